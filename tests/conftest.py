@@ -1,0 +1,79 @@
+"""Shared test plumbing: the ``gpu`` marker, fixture loading, path setup.
+
+``tests/`` is one of the three places allowed to import ``oracle/`` (the checker)."""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+for p in (ROOT, ROOT / "oracle"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+GOLDEN_DIR = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names(variant=None):
+    names = []
+    for f in sorted(GOLDEN_DIR.glob("*.npz")):
+        if variant is not None:
+            with np.load(f) as z:
+                if str(z["variant"]) != variant:
+                    continue
+        names.append(f.stem)
+    return names
+
+
+def load_fixture(name: str) -> SimpleNamespace:
+    """Rebuild the exact input the reference saw (zeros outside the stored DM-RS columns)."""
+    from srsran_ce_pytorch_amd import synth as S
+
+    with np.load(GOLDEN_DIR / f"{name}.npz") as z:
+        case = json.loads(str(z["case_json"]))
+        cols = z["cols"]
+        gc = z["grid_cols"]
+        grids = np.zeros((gc.shape[0], gc.shape[1], case["n_sym"]), np.complex64)
+        grids[:, :, cols] = gc
+        fx = SimpleNamespace(case=case, variant=str(z["variant"]), pilots=z["pilots"], grids=grids,
+                             ref_ch_est=z["ref_ch_est"], ref_scalars=z["ref_scalars"])
+    hops = [S._hop_arrays(case, h) for h in case["hops"]]
+    fx.hop1 = hops[0]
+    fx.hop2 = hops[1] if len(hops) > 1 else S.empty_hop_arrays()
+    fx.config = SimpleNamespace(scs=case["scs"], CyclicPrefixDurations=S.normal_cp_ms(case["scs"]),
+                                Smoothing=case["smoothing"], CFOCompensate=case["cfo_compensate"])
+    if "cnn_alpha" in case:
+        fx.config.CNNSmoothingAlpha = case["cnn_alpha"]
+    fx.beta = case["beta"]
+    return fx
+
+
+def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what=""):
+    """Comparison protocol used everywhere: channel estimate error relative to the largest
+    reference magnitude; scalars relative, except the residual noise whose floor is rounding
+    noise of the EPRE (it is a difference of nearly equal quantities when nothing is smoothed);
+    TA must match exactly to float64 rounding (it is a multiple of 1/(4096*scs));
+    cfo NaN <=> "not estimated"."""
+    scale = float(np.abs(ref_ch).max())
+    err = float(np.abs(got_ch - ref_ch).max()) / scale
+    assert err <= tol_ch, f"{what}: ch_est rel-max err {err:.3e} > {tol_ch:.1e}"
+    noise, rsrp, epre, ta, cfo = [float(x) for x in got_scalars]
+    r_noise, r_rsrp, r_epre, r_ta, r_cfo = [float(x) for x in ref_scalars]
+    assert abs(rsrp - r_rsrp) <= tol_sc * abs(r_rsrp), f"{what}: rsrp {rsrp} vs {r_rsrp}"
+    assert abs(epre - r_epre) <= tol_sc * abs(r_epre), f"{what}: epre {epre} vs {r_epre}"
+    assert abs(noise - r_noise) <= tol_sc * max(abs(r_noise), 1e-2 * abs(r_epre)), f"{what}: noise {noise} vs {r_noise}"
+    assert abs(ta - r_ta) <= 1e-12 * max(abs(r_ta), 1e-9), f"{what}: time alignment {ta} vs {r_ta}"
+    if np.isnan(r_cfo):
+        assert np.isnan(cfo), f"{what}: cfo should be 'not estimated'"
+    else:
+        assert abs(cfo - r_cfo) <= tol_sc * max(abs(r_cfo), 1.0), f"{what}: cfo {cfo} vs {r_cfo}"
+    return err

@@ -1,0 +1,40 @@
+"""Pin the CPU oracle to the real reference: every committed fixture (inputs + outputs of
+``ce_rule_tensorized`` / ``ce_dl_cnn`` run in the build container, tools/make_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import check_outputs, golden_names, load_fixture
+
+import ce_oracle as O
+
+TOL_CH = 2e-6    # both sides are complex64 pipelines; measured <= 5e-7
+TOL_SC = 2e-6
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_fixture(name):
+    fx = load_fixture(name)
+    interp = "linear" if fx.variant == "T" else "cnn"
+    for it in range(fx.grids.shape[0]):
+        out = O.srs_channel_estimator(fx.grids[it], fx.pilots, fx.beta, fx.hop1, fx.hop2, fx.config, interp=interp)
+        sc = [out[1], out[2], out[3], out[4], np.nan if out[5] is None else out[5]]
+        check_outputs(out[0], sc, fx.ref_ch_est[it], fx.ref_scalars[it], TOL_CH, TOL_SC, f"{name}[{it}]")
+
+
+def test_rc_filter_known_taps():
+    """Tap values quoted in SURVEY.md section 8a for stride 2 / 3 RB (15 taps)."""
+    rc = O.get_rc_filter(2, 3)
+    assert rc.size == 15 and abs(rc.sum() - 1) < 1e-15
+    np.testing.assert_allclose(rc[:8], [-0.039159, -0.028799, 0, 0.044525, 0.097072, 0.146705, 0.182153, 0.195006], atol=1e-6)
+    assert [O.get_rc_filter(*a).size for a in [(2, 1), (2, 2), (1, 3), (3, 3)]] == [5, 11, 31, 11]
+
+
+def test_error_conventions():
+    with pytest.raises(ValueError):
+        O.get_rc_filter(0, 3)
+    with pytest.raises(ValueError):
+        O.create_virtual_pilots(np.ones(3, np.complex64), -1)
+    fx = load_fixture("prb1_filter")
+    fx.config.Smoothing = "bogus"
+    with pytest.raises(ValueError):
+        O.srs_channel_estimator(fx.grids[0], fx.pilots, fx.beta, fx.hop1, fx.hop2, fx.config)

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference/src).
+
+Runs only in the build container (the reference never travels to the GPU box).  Each fixture
+holds the seeded synthetic inputs (the build's own generator, srsran_ce_pytorch_amd/synth.py)
+and the six outputs of ``ce_rule_tensorized.srs_channel_estimator`` ("T") or, for the ``cnn_*``
+cases, ``ce_dl_cnn.srs_channel_estimator`` ("C").  ``ce_rule_baseline`` is run on the same input
+and its agreement with T is recorded in ``tests/golden/MANIFEST.json``.
+
+Storage: the reference only reads DM-RS symbols of the grid, so fixtures keep just those
+columns (``grid_cols``); every other RE of the input grid is zero, both when the reference was
+run and when a test rebuilds the grid (``load_fixture`` in tests/conftest.py).
+
+Usage:  python tools/make_golden.py
+"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, "/root/reference/src")
+
+import ce_dl_cnn as REF_C            # noqa: E402
+import ce_rule_baseline as REF_B     # noqa: E402
+import ce_rule_tensorized as REF_T   # noqa: E402
+
+from srsran_ce_pytorch_amd import synth as S   # noqa: E402
+
+H, CS = S.hop_spec, S.case_spec
+BOTH = [S.TYPE1_CDM0, S.TYPE1_CDM1]
+
+
+def golden_cases():
+    cases = [
+        (S.config1_case(), "T", 2),
+        (S.bench_case("none"), "T", 1),
+        (S.bench_case("filter"), "T", 1),
+        (S.bench_case("mean"), "T", 1),
+        (dict(S.bench_case("filter", seed=99), name="pusch273_filter_nocfo", cfo_compensate=False), "T", 1),
+        (CS("case0like_3prb_4dmrs", 52, [H([0, 4, 8, 12], 40, 3)], scs=15e3, seed=3), "T", 2),
+        (CS("hop2_1dmrs_each", 52, [H([2], 3, 3, 0, 7), H([9], 28, 3, 7, 7)], scs=15e3, seed=4), "T", 2),
+        (CS("hop2_2dmrs_each", 52, [H([1, 5], 3, 3, 0, 7), H([8, 12], 28, 3, 7, 7)], scs=15e3, seed=5), "T", 2),
+        (CS("hop2_mean", 52, [H([1, 5], 3, 4, 0, 7), H([8, 12], 20, 4, 7, 7)], smoothing="mean", seed=15), "T", 1),
+        (CS("layers2_6prb", 52, [H([2, 11], 5, 6)], n_layers=2, seed=6), "T", 2),
+        (CS("layers3_6prb", 52, [H([2, 11], 5, 6, re_masks=BOTH)], n_layers=3, seed=7), "T", 2),
+        (CS("layers4_6prb", 52, [H([2, 11], 5, 6, re_masks=BOTH)], n_layers=4, seed=8), "T", 2),
+        (CS("layers4_none", 52, [H([2, 11], 5, 6, re_masks=BOTH)], n_layers=4, smoothing="none", seed=16), "T", 1),
+        (CS("layers2_hop2", 52, [H([1, 5], 3, 3, 0, 7, BOTH[:1]), H([8, 12], 28, 3, 7, 7, BOTH[:1])], n_layers=2, seed=17), "T", 1),
+        (CS("prb1_filter", 52, [H([2, 11], 7, 1)], seed=9), "T", 2),
+        (CS("prb2_filter", 52, [H([2, 11], 7, 2)], seed=10), "T", 2),
+        (CS("type2_5prb", 52, [H([2, 11], 4, 5, re_masks=[S.TYPE2_CDM0])], seed=11), "T", 2),
+        (CS("type2_layers3", 52, [H([2, 7, 11], 4, 5, re_masks=[S.TYPE2_CDM0, S.TYPE2_CDM1])], n_layers=3, seed=12), "T", 1),
+        (CS("partial_symbols_nocfo", 52, [H([3, 10], 4, 8, 2, 10)], seed=13, cfo_compensate=False), "T", 1),
+        (CS("dmrs3_scs15", 25, [H([2, 7, 11], 0, 25)], scs=15e3, seed=18), "T", 1),
+        (CS("layers4_273", 273, [H([2, 11], 0, 273, re_masks=BOTH)], n_layers=4, seed=14), "T", 1),
+        (CS("cnn_3prb", 52, [H([2, 11], 7, 3)], seed=20), "C", 2),
+        (CS("cnn_type2_3prb", 52, [H([2, 11], 7, 3, re_masks=[S.TYPE2_CDM0])], seed=21), "C", 2),
+        (CS("cnn_type2_2hop", 52, [H([2], 3, 3, 0, 7, [S.TYPE2_CDM0]), H([9], 28, 3, 7, 7, [S.TYPE2_CDM0])], seed=23), "C", 1),
+        (dict(CS("cnn_alpha05_3prb", 52, [H([2, 11], 7, 3)], seed=22), cnn_alpha=0.5), "C", 1),
+        (dict(CS("cnn_layers2_alpha", 52, [H([2, 11], 5, 6)], n_layers=2, seed=24), cnn_alpha=0.3), "C", 1),
+        (dict(S.bench_case("filter", seed=77), name="cnn_pusch273_filter"), "C", 1),
+    ]
+    return cases
+
+
+def _ref_hop(mod, ha):
+    return mod.HopConfig(torch.as_tensor(ha.DMRSsymbols), torch.as_tensor(ha.DMRSREmask), ha.PRBstart, ha.nPRBs,
+                         torch.as_tensor(ha.maskPRBs), ha.startSymbol, ha.nAllocatedSymbols)
+
+
+def run_ref(mod, b, grid, case):
+    cfg = mod.EstimatorConfig(b.config.scs, torch.as_tensor(b.config.CyclicPrefixDurations),
+                              b.config.Smoothing, b.config.CFOCompensate)
+    if "cnn_alpha" in case:
+        cfg.CNNSmoothingAlpha = case["cnn_alpha"]          # read via hasattr (ce_dl_cnn.py:864)
+    with torch.no_grad():
+        out = mod.srs_channel_estimator(torch.as_tensor(grid), torch.as_tensor(b.pilots), b.beta,
+                                        _ref_hop(mod, b.hop1), _ref_hop(mod, b.hop2), cfg)
+    ch = out[0].numpy()
+    sc = [float(x) for x in out[1:5]]
+    cfo = float(out[5]) if out[5].numel() else float("nan")
+    return ch, np.array(sc + [cfo], np.float64)
+
+
+def main():
+    out_dir = ROOT / "tests" / "golden"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    manifest = {}
+    for case, variant, n_items in golden_cases():
+        b = S.build_case(case, n_items)
+        cols = sorted({s for h in case["hops"] for s in h["dmrs_symbols"]})
+        grids = np.zeros_like(b.grids)
+        grids[:, :, cols] = b.grids[:, :, cols]
+        mod = REF_T if variant == "T" else REF_C
+        chs, scs = [], []
+        worst_b = 0.0
+        for it in range(n_items):
+            ch, sc = run_ref(mod, b, grids[it], case)
+            chs.append(ch)
+            scs.append(sc)
+            if variant == "T":
+                ch_b, sc_b = run_ref(REF_B, b, grids[it], case)
+                worst_b = max(worst_b, float(np.abs(ch_b - ch).max()))
+        np.savez_compressed(out_dir / f"{case['name']}.npz",
+                            case_json=np.array(json.dumps(case)), variant=np.array(variant),
+                            pilots=b.pilots, grid_cols=grids[:, :, cols], cols=np.array(cols, np.int64),
+                            ref_ch_est=np.stack(chs), ref_scalars=np.stack(scs))
+        manifest[case["name"]] = dict(variant=variant, n_items=n_items, baseline_vs_tensorized_max_abs=worst_b,
+                                      scalars=["noise", "rsrp", "epre", "time_alignment", "cfo_hz(nan=not estimated)"])
+        print(f"{case['name']:28s} {variant} items={n_items} |B-T|max={worst_b:.2e} ta={scs[0][3]:.4e} cfo={scs[0][4]:.3f}")
+    (out_dir / "MANIFEST.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
+
+
+if __name__ == "__main__":
+    main()
