@@ -1,0 +1,132 @@
+/*
+ * ce_hip.h -- C ABI of the MI355X (gfx950) PUSCH DM-RS channel-estimation library (libce_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of the reference (pjookim/srsran-ce-pytorch):
+ *     src/ce_rule_tensorized.py:745  srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1, hop2, config)
+ * i.e. process_hop (src/ce_rule_tensorized.py:495-739) for 1-2 hops plus the slot-level epilogue
+ * (src/ce_rule_tensorized.py:898-937), batched over slots x Rx ports.  The reference has no FFI of
+ * its own (it is eager PyTorch); the host side that binds these symbols is
+ * srsran_ce_pytorch_amd/_lib.py (ctypes), see INTEGRATION.md.
+ *
+ * Plain pointers and sizes only -- no torch / C++ types cross this boundary.  All device
+ * pointers must belong to the plan's device.  Every entry point returns 0 on success or a
+ * negative CE_ERR_* code; ce_last_error() gives the message for the calling thread.
+ */
+#ifndef CE_HIP_H
+#define CE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CE_ABI_VERSION 1
+
+#define CE_MAX_LAYERS 4   /* Tx layers (pilots.shape[2]); 2 per CDM group (T:551-552) */
+#define CE_MAX_CDM 2
+#define CE_MAX_HOPS 2
+#define CE_MAX_SYMBOLS 14 /* the reference's CFO ramp assumes a 14-symbol slot (T:928-929) */
+#define CE_FFT_SIZE 4096  /* time-alignment IFFT length (T:677) */
+
+/* config.Smoothing (T:633-668) */
+enum { CE_SMOOTH_NONE = 0, CE_SMOOTH_MEAN = 1, CE_SMOOTH_FILTER = 2 };
+/* frequency interpolation: T:311-340 (linear) or src/ce_dl_cnn.py:292-295 (3-tap in-painting) */
+enum { CE_INTERP_LINEAR = 0, CE_INTERP_CNN = 1 };
+
+enum {
+  CE_OK = 0,
+  CE_ERR_INVALID = -1,     /* malformed descriptor / arguments (maps to ValueError on the host) */
+  CE_ERR_UNSUPPORTED = -2, /* valid for the reference but outside this build's limits */
+  CE_ERR_HIP = -3,         /* a HIP runtime call failed */
+  CE_ERR_NOMEM = -4
+};
+
+/* One frequency hop: mirrors HopConfig (src/ce_rule_tensorized.py:13-21). */
+typedef struct ce_hop_desc {
+  uint8_t dmrs_symbols[CE_MAX_SYMBOLS]; /* DMRSsymbols: 1 where the OFDM symbol carries DM-RS */
+  uint16_t re_mask[CE_MAX_CDM];         /* DMRSREmask column c: bit r set <=> RE r of each PRB is a pilot */
+  int32_t prb_start;                    /* PRBstart  */
+  int32_t n_prbs;                       /* nPRBs     */
+  const uint8_t* mask_prbs;             /* maskPRBs: n_prb_grid bytes (0/1); host memory, read during create */
+  int32_t start_symbol;                 /* startSymbol */
+  int32_t n_alloc_symbols;              /* nAllocatedSymbols */
+} ce_hop_desc;
+
+/* Slot geometry + EstimatorConfig (src/ce_rule_tensorized.py:24-29), resolved once per plan. */
+typedef struct ce_plan_desc {
+  int32_t abi_version;   /* = CE_ABI_VERSION */
+  int32_t device;        /* HIP device ordinal the plan (tables, launches) lives on */
+  int32_t n_prb_grid;    /* grid has 12*n_prb_grid subcarriers (<= 4096 for the TA IFFT, T:679) */
+  int32_t n_sym;         /* OFDM symbols in the grid (14 when the CFO ramp is applied) */
+  int32_t n_layers;      /* 1..CE_MAX_LAYERS */
+  int32_t n_hops;        /* 1 or 2 (hop2 "empty" => 1) */
+  int32_t smoothing;     /* CE_SMOOTH_* */
+  int32_t cfo_compensate;/* config.CFOCompensate */
+  int32_t interp;        /* CE_INTERP_* */
+  int32_t reserved0;
+  double scs_hz;         /* config.scs */
+  double beta_dmrs;      /* betaDMRS */
+  double cp_ms[CE_MAX_SYMBOLS]; /* config.CyclicPrefixDurations[0:14], milliseconds */
+  double cnn_smoothing_alpha;   /* config.CNNSmoothingAlpha (src/ce_dl_cnn.py:864); 0 = off */
+  ce_hop_desc hop[CE_MAX_HOPS];
+} ce_plan_desc;
+
+typedef struct ce_plan ce_plan; /* opaque */
+
+/* Derived facts a host needs to size buffers / shape results. */
+typedef struct ce_plan_info {
+  int32_t n_sc;            /* 12*n_prb_grid */
+  int32_t n_re;            /* pilots per DM-RS symbol per CDM group (= pilots.shape[0]) */
+  int32_t n_dmrs_total;    /* DM-RS symbols over both hops (= pilots.shape[1]) */
+  int32_t cfo_estimated;   /* 1 if some hop has >= 2 DM-RS symbols, else cfo outputs are NaN (T:388-391, T:931-933) */
+  int32_t lds_bytes;       /* dynamic LDS per workgroup */
+  int32_t threads;         /* workgroup size */
+  int64_t alg_bytes_per_item; /* n_re*n_dmrs*8*nCDM + n_sc*n_sym*L*8 (per slot x port) */
+  int64_t pilot_bytes_per_slot; /* n_re*n_dmrs*L*8 */
+} ce_plan_info;
+
+/* Validates the descriptor, derives every per-plan table on the host in float64 (pilot RE index
+ * lists T:571-576, symbol start times T:809-820, CFO sample span T:418-426, RC taps T:184-234,
+ * interpolation anchors T:311-338, IFFT twiddles) and uploads them.  Synchronous; not for the
+ * per-slot hot loop.  Replaces the per-call re-derivation the reference does inside process_hop. */
+int ce_plan_create(const ce_plan_desc* desc, ce_plan** out);
+void ce_plan_destroy(ce_plan* plan);
+int ce_plan_get_info(const ce_plan* plan, ce_plan_info* info);
+
+/*
+ * Estimate n_slots x n_ports work items in ONE kernel launch on `stream` (a hipStream_t; NULL =
+ * the default stream).  Asynchronous: returns after the launch is enqueued.
+ *
+ *  rx            complex64 received grids, element (slot b, port r, subcarrier k, symbol s) at
+ *                rx[b*rx_strides[0] + r*rx_strides[1] + k*rx_strides[2] + s*rx_strides[3]] (strides in
+ *                complex elements).  Any layout works; [slot][port][symbol][subcarrier] (rx_strides[2]==1)
+ *                gives coalesced pilot loads.  Replaces received_rg of T:745 (one (n_sc,n_sym) grid per item).
+ *  pilots        complex64 DM-RS symbols, element (slot b, re k, dmrs symbol s, layer l) at
+ *                pilots[b*pil_strides[0] + k*pil_strides[1] + s*pil_strides[2] + l*pil_strides[3]];
+ *                pil_strides[0]==0 shares one pilot set across the batch.  Axis order of T:760.
+ *                The Rx ports of a slot always share pilots.
+ *  ch_est        out, complex64, dense [slot][port][subcarrier][symbol][layer] (the reference's
+ *                (n_sc,n_sym,L) layout per item, T:766); EVERY element is written (zeros outside hops).
+ *  noise,rsrp,epre,ta,cfo_hz   out, float64 [slot][port] each (T:767-771); cfo_hz = NaN when not estimated.
+ */
+int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
+                      const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est,
+                      double* noise, double* rsrp, double* epre, double* ta, double* cfo_hz, void* stream);
+
+/* Times `iters` back-to-back launches of ce_estimate_batch with HIP events recorded on `stream`
+ * (after `warmup` untimed ones); *avg_ms = mean kernel-launch duration.  Used by bench.py for the
+ * roofline line.  Synchronous. */
+int ce_time_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
+                  const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est, double* noise,
+                  double* rsrp, double* epre, double* ta, double* cfo_hz, void* stream, int32_t warmup,
+                  int32_t iters, double* avg_ms);
+
+const char* ce_last_error(void);
+int ce_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CE_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libce_hip.so (C ABI: include/ce_hip.h) and the in-tree build recipe.
+
+The product path has no CPU fallback: if the library is missing or fails to load,
+``load()`` raises and every estimator entry point with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+INCLUDE = PKG_DIR.parent / "include"
+LIB_PATH = CSRC / "libce_hip.so"
+SOURCES = ["ce_api.hip", "ce_kernels.hip"]
+
+CE_ABI_VERSION = 1
+CE_MAX_CDM, CE_MAX_HOPS, CE_MAX_SYMBOLS = 2, 2, 14
+SMOOTHING = {"none": 0, "mean": 1, "filter": 2}
+INTERP = {"linear": 0, "cnn": 1}
+CE_ERR_INVALID, CE_ERR_UNSUPPORTED, CE_ERR_HIP, CE_ERR_NOMEM = -1, -2, -3, -4
+
+
+class HopDesc(C.Structure):
+    _fields_ = [("dmrs_symbols", C.c_uint8 * CE_MAX_SYMBOLS), ("re_mask", C.c_uint16 * CE_MAX_CDM),
+                ("prb_start", C.c_int32), ("n_prbs", C.c_int32), ("mask_prbs", C.POINTER(C.c_uint8)),
+                ("start_symbol", C.c_int32), ("n_alloc_symbols", C.c_int32)]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_prb_grid", C.c_int32), ("n_sym", C.c_int32),
+                ("n_layers", C.c_int32), ("n_hops", C.c_int32), ("smoothing", C.c_int32),
+                ("cfo_compensate", C.c_int32), ("interp", C.c_int32), ("reserved0", C.c_int32),
+                ("scs_hz", C.c_double), ("beta_dmrs", C.c_double), ("cp_ms", C.c_double * CE_MAX_SYMBOLS),
+                ("cnn_smoothing_alpha", C.c_double), ("hop", HopDesc * CE_MAX_HOPS)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("n_sc", C.c_int32), ("n_re", C.c_int32), ("n_dmrs_total", C.c_int32), ("cfo_estimated", C.c_int32),
+                ("lds_bytes", C.c_int32), ("threads", C.c_int32), ("alg_bytes_per_item", C.c_int64),
+                ("pilot_bytes_per_slot", C.c_int64)]
+
+
+EXPORTS = ["ce_plan_create", "ce_plan_destroy", "ce_plan_get_info", "ce_estimate_batch", "ce_time_batch",
+           "ce_last_error", "ce_abi_version"]
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950 -> csrc/libce_hip.so (cross-compiles without a GPU)."""
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + [CSRC / "ce_plan.h", INCLUDE / "ce_hip.h"]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
+           "-o", str(LIB_PATH)] + [str(s) for s in srcs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the estimator has no CPU fallback)")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i64p, dp = C.c_void_p, C.POINTER(C.c_int64), C.c_void_p
+    lib.ce_plan_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(vp)]
+    lib.ce_plan_create.restype = C.c_int
+    lib.ce_plan_destroy.argtypes = [vp]
+    lib.ce_plan_destroy.restype = None
+    lib.ce_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    lib.ce_plan_get_info.restype = C.c_int
+    batch = [vp, vp, i64p, vp, i64p, C.c_int64, C.c_int32, vp, dp, dp, dp, dp, dp, vp]
+    lib.ce_estimate_batch.argtypes = batch
+    lib.ce_estimate_batch.restype = C.c_int
+    lib.ce_time_batch.argtypes = batch + [C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    lib.ce_time_batch.restype = C.c_int
+    lib.ce_last_error.argtypes = []
+    lib.ce_last_error.restype = C.c_char_p
+    lib.ce_abi_version.argtypes = []
+    lib.ce_abi_version.restype = C.c_int
+    if lib.ce_abi_version() != CE_ABI_VERSION:
+        raise RuntimeError(f"libce_hip.so ABI {lib.ce_abi_version()} != binding {CE_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ce_last_error().decode("utf-8", "replace")

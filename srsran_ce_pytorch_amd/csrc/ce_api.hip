@@ -1,0 +1,324 @@
+// Host side of libce_hip.so: descriptor validation, float64 derivation of every per-plan table,
+// upload, launch and HIP-event timing.  C ABI declared in include/ce_hip.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "ce_plan.h"
+
+struct ce_plan {
+  ce_plan_desc desc;
+  CeDevPlan host;
+  CeDevPlan* dev_plan = nullptr;
+  uint16_t* dev_re_idx = nullptr;
+  float2* dev_tw = nullptr;
+  ce_plan_info info;
+  int device = 0;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) return fail(CE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// Raised-cosine taps: rcosdesign(0.2, n_rbs, 10) sampled every `stride`, unit sum (T:143-234).
+std::vector<double> rc_taps(int stride, int n_rbs) {
+  const double beta = 0.2;
+  const int sps = 10, half_n = n_rbs * sps / 2, len = 2 * half_n + 1;
+  std::vector<double> ff(len);
+  for (int i = 0; i < len; ++i) {
+    const double t = (double)(i - half_n) / sps;
+    const double sinc = (t == 0.0) ? 1.0 : sin(M_PI * t) / (M_PI * t);
+    const double den = 1.0 - (2.0 * beta * t) * (2.0 * beta * t);
+    double h = sinc * cos(M_PI * beta * t) / den;
+    if (!isfinite(h) || fabs(fabs(t) - 1.0 / (2.0 * beta)) < (1.0 / sps) * 1e-6)
+      h = (M_PI * beta / 2.0) * sin(1.0 / (2.0 * beta));
+    ff[i] = h;
+  }
+  const int half = len / 2, kmax = (half / stride) * stride, center = (len - 1) / 2;
+  std::vector<double> taps;
+  double sum = 0.0;
+  for (int k = -kmax; k <= kmax; k += stride) {
+    taps.push_back(ff[k + center]);
+    sum += ff[k + center];
+  }
+  for (double& v : taps) v /= sum;
+  return taps;
+}
+
+int popcount12(unsigned m) { return __builtin_popcount(m & 0xFFFu); }
+
+}  // namespace
+
+extern "C" {
+
+const char* ce_last_error(void) { return g_err.c_str(); }
+int ce_abi_version(void) { return CE_ABI_VERSION; }
+
+int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
+  if (!d || !out) return fail(CE_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (d->abi_version != CE_ABI_VERSION) return fail(CE_ERR_INVALID, "ABI version %d != %d", d->abi_version, CE_ABI_VERSION);
+  if (d->n_layers < 1 || d->n_layers > CE_MAX_LAYERS) return fail(CE_ERR_UNSUPPORTED, "n_layers=%d outside 1..%d", d->n_layers, CE_MAX_LAYERS);
+  if (d->n_hops < 1 || d->n_hops > CE_MAX_HOPS) return fail(CE_ERR_INVALID, "n_hops=%d outside 1..2", d->n_hops);
+  if (d->n_prb_grid < 1 || 12 * d->n_prb_grid > CE_FFT_SIZE)
+    return fail(CE_ERR_UNSUPPORTED, "grid of %d PRB: the time-alignment IFFT (T:679) needs 12*n_prb <= %d", d->n_prb_grid, CE_FFT_SIZE);
+  if (d->n_sym < 1 || d->n_sym > CE_MAX_SYMBOLS) return fail(CE_ERR_UNSUPPORTED, "n_sym=%d outside 1..%d", d->n_sym, CE_MAX_SYMBOLS);
+  if (d->smoothing < CE_SMOOTH_NONE || d->smoothing > CE_SMOOTH_FILTER) return fail(CE_ERR_INVALID, "Unknown smoothing strategy %d.", d->smoothing);
+  if (d->interp != CE_INTERP_LINEAR) return fail(CE_ERR_UNSUPPORTED, "interp=%d: only linear interpolation is built", d->interp);
+  if (!(d->scs_hz > 0) || !(d->beta_dmrs > 0)) return fail(CE_ERR_INVALID, "scs and beta_dmrs must be positive");
+
+  ce_plan* p = new (std::nothrow) ce_plan();
+  if (!p) return fail(CE_ERR_NOMEM, "out of host memory");
+  p->desc = *d;
+  p->device = d->device;
+  CeDevPlan& P = p->host;
+  memset(&P, 0, sizeof(P));
+  const int L = d->n_layers, n_cdm = (L + 1) / 2, n_sc = 12 * d->n_prb_grid;
+  P.n_sc = n_sc; P.n_sym = d->n_sym; P.n_layers = L; P.n_cdm = n_cdm; P.n_hops = d->n_hops;
+  P.smoothing = d->smoothing; P.cfo_comp = d->cfo_compensate ? 1 : 0; P.interp = d->interp;
+  P.beta = d->beta_dmrs; P.beta_f = (float)d->beta_dmrs; P.scs = d->scs_hz; P.denom_cdm = (double)n_cdm;
+
+  // symbolStartTime = cumsum([CPD0, CPD1..13 + 1]), CPD = cp_ms*scs/1000 (T:809-820)
+  {
+    double acc = 0.0;
+    for (int s = 0; s < CE_MAX_SYMBOLS; ++s) {
+      const double cpd = d->cp_ms[s] * d->scs_hz / 1000.0;
+      acc += (s == 0) ? cpd : cpd + 1.0;
+      P.sst[s] = acc;
+    }
+  }
+
+  std::vector<uint16_t> re_idx;
+  int n_re = -1, n_dmrs_total = 0, cfo_estimated = 0;
+  uint8_t seen_sym[CE_MAX_SYMBOLS] = {0};
+  for (int h = 0; h < d->n_hops; ++h) {
+    const ce_hop_desc& hd = d->hop[h];
+    CeDevHop& H = P.hop[h];
+    if (!hd.mask_prbs) { delete p; return fail(CE_ERR_INVALID, "hop %d: mask_prbs is null", h); }
+    for (int s = 0; s < d->n_sym; ++s)
+      if (hd.dmrs_symbols[s]) {
+        if (seen_sym[s]) { delete p; return fail(CE_ERR_INVALID, "Hops should not overlap."); }
+        seen_sym[s] = 1;
+        H.dmrs_sym[H.n_dmrs++] = s;
+      }
+    if (H.n_dmrs < 1) { delete p; return fail(CE_ERR_INVALID, "hop %d has no DM-RS symbol", h); }
+    if (h == 1 && (hd.re_mask[0] != d->hop[0].re_mask[0] || (n_cdm > 1 && hd.re_mask[1] != d->hop[0].re_mask[1]))) {
+      delete p;
+      return fail(CE_ERR_INVALID, "The DM-RS mask should be the same for the two hops.");
+    }
+    H.pil_sym0 = n_dmrs_total;
+    n_dmrs_total += H.n_dmrs;
+    H.has_cfo = H.n_dmrs >= 2;
+    cfo_estimated |= H.has_cfo;
+    if (hd.prb_start < 0 || hd.n_prbs < 1 || hd.prb_start + hd.n_prbs > d->n_prb_grid) {
+      delete p;
+      return fail(CE_ERR_INVALID, "hop %d: PRBstart=%d nPRBs=%d outside the %d-PRB grid", h, hd.prb_start, hd.n_prbs, d->n_prb_grid);
+    }
+    if (hd.start_symbol < 0 || hd.n_alloc_symbols < 0 || hd.start_symbol + hd.n_alloc_symbols > d->n_sym) {
+      delete p;
+      return fail(CE_ERR_INVALID, "hop %d: symbols %d..+%d outside the %d-symbol grid", h, hd.start_symbol, hd.n_alloc_symbols, d->n_sym);
+    }
+    H.sc0 = 12 * hd.prb_start; H.n_sc_hop = 12 * hd.n_prbs;
+    H.sym0 = hd.start_symbol; H.sym1 = hd.start_symbol + hd.n_alloc_symbols;
+    int n_active = 0;
+    for (int q = 0; q < d->n_prb_grid; ++q) n_active += hd.mask_prbs[q] ? 1 : 0;
+    if (n_active != hd.n_prbs) {
+      delete p;
+      return fail(CE_ERR_INVALID, "hop %d: sum(maskPRBs)=%d != nPRBs=%d (the reference's grid fill T:291-292 needs them equal)", h, n_active, hd.n_prbs);
+    }
+    for (int c = 0; c < n_cdm; ++c) {
+      const unsigned m = hd.re_mask[c] & 0xFFFu;
+      const int dpp = popcount12(m);
+      if (dpp == 0) { delete p; return fail(CE_ERR_INVALID, "hop %d: DMRSREmask column %d is empty", h, c); }
+      H.dpp[c] = dpp;
+      H.re_off[c] = (int)re_idx.size();
+      // maskREs = kron(maskPRBs, DMRSREmask[:, c]) (T:572-576)
+      for (int q = 0; q < d->n_prb_grid; ++q)
+        if (hd.mask_prbs[q])
+          for (int r = 0; r < 12; ++r)
+            if (m >> r & 1) re_idx.push_back((uint16_t)(12 * q + r));
+      const int cnt = (int)re_idx.size() - H.re_off[c];
+      if (n_re < 0) n_re = cnt;
+      if (cnt != n_re) {
+        delete p;
+        return fail(CE_ERR_INVALID, "hop %d CDM %d has %d pilot REs, expected %d (pilots.shape[0] is shared)", h, c, cnt, n_re);
+      }
+      // interpolation anchors, periodic in the PRB (T:311-338)
+      int first_r = 0, last_r = 11;
+      while (!(m >> first_r & 1)) ++first_r;
+      while (!(m >> last_r & 1)) --last_r;
+      H.last_idx[c] = 12 * (hd.n_prbs - 1) + last_r;
+      for (int r = 0; r < 12; ++r) {
+        int rr = r;  // right anchor: first pilot at or after r (possibly in the next PRB)
+        while (rr < 12 && !(m >> rr & 1)) ++rr;
+        int right_pos, ord;
+        if (rr < 12) { right_pos = rr; ord = popcount12(m & ((1u << rr) - 1u)); }
+        else { right_pos = 12 + first_r; ord = dpp; }
+        int lp = (rr < 12 ? rr : 12) - 1;  // left anchor: the pilot before the right anchor
+        while (lp >= 0 && !(m >> lp & 1)) --lp;
+        const int left_pos = lp >= 0 ? lp : last_r - 12;
+        H.r_ord[c][r] = ord;
+        H.alpha[c][r] = (float)(r - left_pos) / (float)(right_pos - left_pos);
+      }
+    }
+    // nSamples = nSyms + sum(CPDs(i0+1 .. i1)), CPDs = cp_ms * (scs/1000) (T:395-426, called with scs/1000 at T:599)
+    if (H.has_cfo) {
+      const int i0 = H.dmrs_sym[0], i1 = H.dmrs_sym[1];
+      double cp_sum = 0.0;
+      for (int s = i0 + 1; s <= i1 && s < CE_MAX_SYMBOLS; ++s) cp_sum += d->cp_ms[s] * (d->scs_hz / 1000.0);
+      H.two_pi_nsamples = 2.0 * M_PI * ((double)(i1 - i0) + cp_sum);
+    }
+  }
+  P.n_re = n_re; P.n_re_pad = (n_re + 1) & ~1;
+  P.cfo_estimated = cfo_estimated;
+  if (P.cfo_comp && cfo_estimated && d->n_sym != CE_MAX_SYMBOLS) {
+    delete p;
+    return fail(CE_ERR_INVALID, "CFO compensation needs a 14-symbol grid (T:928-929), got %d", d->n_sym);
+  }
+
+  // nPilots = hop1.nPRBs * sum(hop1.DMRSREmask(:,1)) * nDMRSsymbols (T:898-915)
+  const double n_pilots = (double)(d->hop[0].n_prbs * P.hop[0].dpp[0] * n_dmrs_total);
+  P.n_pilots = n_pilots;
+  P.noise_den = (double)n_cdm * n_pilots - 1.0;
+
+  if (d->smoothing == CE_SMOOTH_FILTER) {
+    const int dpp0 = P.hop[0].dpp[0];
+    if (12 % dpp0 != 0) { delete p; return fail(CE_ERR_UNSUPPORTED, "%d pilots per PRB does not divide 12 (T:640)", dpp0); }
+    const int n_active = d->hop[0].n_prbs;
+    std::vector<double> rc = rc_taps(12 / dpp0, n_active < 3 ? n_active : 3);
+    if ((int)rc.size() > CE_MAX_RC_TAPS) { delete p; return fail(CE_ERR_UNSUPPORTED, "%zu RC taps", rc.size()); }
+    P.rc_len = (int)rc.size();
+    for (size_t i = 0; i < rc.size(); ++i) P.rc[i] = rc[i];
+    P.n_pils = n_active > 1 ? ((int)rc.size() / 2 < 12 ? (int)rc.size() / 2 : 12) : dpp0;  // T:644-647
+    if (P.n_pils > n_re || P.n_pils < 1) { delete p; return fail(CE_ERR_UNSUPPORTED, "n_pils=%d vs n_re=%d", P.n_pils, n_re); }
+    P.ext_len = n_re + 2 * P.n_pils;
+    P.filt_lpp = CE_FFT_SIZE / P.ext_len;
+    if (P.filt_lpp < 1) { delete p; return fail(CE_ERR_UNSUPPORTED, "band of %d pilots too wide for the LDS scratch", n_re); }
+    if (P.filt_lpp > L) P.filt_lpp = L;
+  }
+
+  const CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad);
+  if (lay.total > 160 * 1024) { delete p; return fail(CE_ERR_UNSUPPORTED, "plan needs %d B of LDS (> 160 KiB)", lay.total); }
+
+  ce_plan_info& I = p->info;
+  I.n_sc = n_sc; I.n_re = n_re; I.n_dmrs_total = n_dmrs_total; I.cfo_estimated = cfo_estimated;
+  I.lds_bytes = lay.total; I.threads = CE_THREADS;
+  I.alg_bytes_per_item = (int64_t)n_re * n_dmrs_total * 8 * n_cdm + (int64_t)n_sc * d->n_sym * L * 8;
+  I.pilot_bytes_per_slot = (int64_t)n_re * n_dmrs_total * L * 8;
+
+  // IFFT twiddles exp(+j*2*pi*m/4096), float64 -> float32
+  std::vector<float2> tw(CE_FFT_SIZE);
+  for (int m = 0; m < CE_FFT_SIZE; ++m) {
+    const double a = 2.0 * M_PI * (double)m / (double)CE_FFT_SIZE;
+    tw[m] = make_float2((float)cos(a), (float)sin(a));
+  }
+
+  hipError_t e = hipSetDevice(d->device);
+  if (e == hipSuccess) e = hipMalloc(&p->dev_plan, sizeof(CeDevPlan));
+  if (e == hipSuccess) e = hipMalloc(&p->dev_re_idx, re_idx.size() * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMalloc(&p->dev_tw, tw.size() * sizeof(float2));
+  if (e == hipSuccess) e = hipMemcpy(p->dev_plan, &P, sizeof(CeDevPlan), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->dev_re_idx, re_idx.data(), re_idx.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->dev_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = (hipError_t)ce_prepare_kernel(L, P.n_hops, lay.total);
+  if (e != hipSuccess) {
+    fail(CE_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+    ce_plan_destroy(p);
+    return CE_ERR_HIP;
+  }
+  *out = p;
+  return CE_OK;
+}
+
+void ce_plan_destroy(ce_plan* p) {
+  if (!p) return;
+  if (p->dev_plan) (void)hipFree(p->dev_plan);
+  if (p->dev_re_idx) (void)hipFree(p->dev_re_idx);
+  if (p->dev_tw) (void)hipFree(p->dev_tw);
+  delete p;
+}
+
+int ce_plan_get_info(const ce_plan* plan, ce_plan_info* info) {
+  if (!plan || !info) return fail(CE_ERR_INVALID, "null argument");
+  *info = plan->info;
+  return CE_OK;
+}
+
+static int check_batch(const ce_plan* plan, const void* rx, const int64_t* rs, const void* pilots, const int64_t* ps,
+                       int64_t n_slots, int32_t n_ports, void* ch_est, double* noise, double* rsrp, double* epre,
+                       double* ta, double* cfo, CeKernelArgs* a) {
+  if (!plan || !rx || !rs || !pilots || !ps || !ch_est || !noise || !rsrp || !epre || !ta || !cfo)
+    return fail(CE_ERR_INVALID, "null argument");
+  if (n_slots < 0 || n_ports < 1) return fail(CE_ERR_INVALID, "n_slots=%lld n_ports=%d", (long long)n_slots, n_ports);
+  if (n_slots * n_ports > 0x7FFFFFFFll) return fail(CE_ERR_UNSUPPORTED, "more than 2^31-1 work items in one launch");
+  for (int i = 0; i < 4; ++i)
+    if (rs[i] < 0 || ps[i] < 0) return fail(CE_ERR_INVALID, "negative strides are not supported");
+  a->rx = (const float2*)rx; a->rs_b = rs[0]; a->rs_r = rs[1]; a->rs_sc = rs[2]; a->rs_sym = rs[3];
+  a->pil = (const float2*)pilots; a->ps_b = ps[0]; a->ps_re = ps[1]; a->ps_sym = ps[2]; a->ps_l = ps[3];
+  a->out = (float2*)ch_est; a->noise = noise; a->rsrp = rsrp; a->epre = epre; a->ta = ta; a->cfo = cfo;
+  a->n_items = n_slots * n_ports; a->n_ports = n_ports;
+  return CE_OK;
+}
+
+int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
+                      const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est, double* noise,
+                      double* rsrp, double* epre, double* ta, double* cfo_hz, void* stream) {
+  CeKernelArgs a;
+  int rc = check_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, &a);
+  if (rc != CE_OK) return rc;
+  if (a.n_items == 0) return CE_OK;
+  int e = ce_launch(plan->host, plan->dev_plan, plan->dev_re_idx, plan->dev_tw, a, plan->info.lds_bytes, (hipStream_t)stream);
+  if (e != 0) return fail(CE_ERR_HIP, "kernel launch failed: %s", e > 0 ? hipGetErrorString((hipError_t)e) : "no kernel for this (layers, hops)");
+  return CE_OK;
+}
+
+int ce_time_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
+                  const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est, double* noise,
+                  double* rsrp, double* epre, double* ta, double* cfo_hz, void* stream, int32_t warmup, int32_t iters,
+                  double* avg_ms) {
+  if (!avg_ms || iters < 1 || warmup < 0) return fail(CE_ERR_INVALID, "bad timing arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < warmup; ++i) {
+    int rc = ce_estimate_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, stream);
+    if (rc != CE_OK) return rc;
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) {
+    int rc = ce_estimate_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, stream);
+    if (rc != CE_OK) return rc;
+  }
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = (double)ms / iters;
+  return CE_OK;
+}
+
+}  // extern "C"

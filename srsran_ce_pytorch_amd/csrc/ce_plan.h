@@ -1,0 +1,70 @@
+// Device-resident plan: everything process_hop() re-derives per call in the reference
+// (src/ce_rule_tensorized.py:563-576, 638-647, 809-820) resolved once on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ce_hip.h"
+
+#define CE_MAX_RC_TAPS 31   // stride 1, 3 RB (T:184-234)
+#define CE_TA_HALF 144      // floor(72 * 4096 / 2048) bins each side (T:682)
+#define CE_THREADS 256
+
+struct CeDevHop {
+  int32_t n_dmrs;                     // DM-RS symbols in the hop
+  int32_t dmrs_sym[CE_MAX_SYMBOLS];   // their OFDM symbol indices (ascending)
+  int32_t pil_sym0;                   // first column of this hop along the pilots' symbol axis (T:823, T:871)
+  int32_t sc0, n_sc_hop;              // fill window 12*PRBstart .. +12*nPRBs (T:301-304)
+  int32_t sym0, sym1;                 // fill symbols [startSymbol, startSymbol+nAllocatedSymbols) (T:306-309)
+  int32_t has_cfo;                    // n_dmrs >= 2 (T:388)
+  int32_t re_off[CE_MAX_CDM];         // offset of the CDM group's pilot subcarrier list in the re_idx table
+  int32_t last_idx[CE_MAX_CDM];       // hop-relative position of the last pilot RE (T:314)
+  int32_t dpp[CE_MAX_CDM];            // pilots per PRB of the CDM group
+  int32_t r_ord[CE_MAX_CDM][12];      // right-anchor ordinal inside the PRB for RE r (T:325)
+  float alpha[CE_MAX_CDM][12];        // (pos-left)/(right-left) in float32 (T:333-337)
+  double two_pi_nsamples;             // 2*pi*nSamples (T:418-426)
+};
+
+struct CeDevPlan {
+  int32_t n_sc, n_sym, n_layers, n_cdm, n_hops, smoothing, cfo_comp, interp;
+  int32_t n_re, n_re_pad, n_pils, rc_len, ext_len, filt_lpp;
+  int32_t cfo_estimated, apply_final_rot_possible;
+  float beta_f;
+  double beta, scs, denom_cdm, n_pilots, noise_den;
+  double sst[CE_MAX_SYMBOLS];         // symbolStartTime (T:809-820)
+  double rc[CE_MAX_RC_TAPS];          // RC taps, unit sum (T:184-234)
+  CeDevHop hop[CE_MAX_HOPS];
+};
+
+struct CeKernelArgs {
+  const float2* rx;
+  int64_t rs_b, rs_r, rs_sc, rs_sym;
+  const float2* pil;
+  int64_t ps_b, ps_re, ps_sym, ps_l;
+  float2* out;
+  double *noise, *rsrp, *epre, *ta, *cfo;
+  int64_t n_items;
+  int32_t n_ports;
+};
+
+// LDS carve-up shared by host (sizing) and device (offsets); all offsets multiples of 16 B.
+struct CeLdsLayout {
+  int32_t off_p, off_scratch, off_red, off_rot, off_tab, off_misc, total;
+};
+
+static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_layers, int n_re_pad) {
+  CeLdsLayout l;
+  int o = 0;
+  l.off_p = o;        o += n_hops * n_layers * n_re_pad * 8;
+  l.off_scratch = o;  o += CE_FFT_SIZE * 8;
+  l.off_red = o;      o += (CE_THREADS / 64) * 16 * 8;           // 16 doubles per wave
+  l.off_rot = o;      o += (1 + 2 * CE_MAX_HOPS) * 16 * 8;       // final, per-hop -/+ phasors, 16 float2 each
+  l.off_tab = o;      o += CE_MAX_HOPS * CE_MAX_CDM * 12 * 8;    // {alpha, r_ord} pairs
+  l.off_misc = o;     o += 16 * 8;                               // doubles: cfo_hop[2], cfo_final, ...
+  l.total = (o + 15) & ~15;
+  return l;
+}
+
+int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const float2* tw,
+              const CeKernelArgs& args, int lds_bytes, hipStream_t stream);
+int ce_prepare_kernel(int n_layers, int n_hops, int lds_bytes);
