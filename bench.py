@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: slots/sec of the fused PUSCH DM-RS channel-estimation path at 273 PRB.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 under torch.distributed.run, one
+rank per GPU).  A *step* is one pass of the hot path over one resident batch of synthetic slots
+(one fused kernel launch per rank).  The slot batch is sharded across ranks with NO data-path
+collective (slots are independent) -> weak scaling: every rank owns ``--slots`` slots.
+
+Workloads (BASELINE.json configs):
+  pusch273_4rx_filter   configs[2]: 273 PRB / 4 Rx / 8192 slots per GPU, Smoothing="filter" -- the
+                        reference's own frequency smoothing (it has no MMSE/Wiener mode).
+                        This is the configuration the metric ("273-PRB PUSCH, 4 Rx") is quoted on.
+  pusch273_1rx_none     configs[1]: LS + linear interpolation, 273 PRB / 1 Rx / 1024 slots.
+
+Prints ONE JSON line on rank 0 with the driver's fields plus ``roofline`` (HBM; algorithmic bytes
+per launch / HIP-event launch time) and, at N=1, ``cpu_baseline`` (the CPU oracle = a port of the
+reference's algorithm, timed on the host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "pusch273_4rx_filter": dict(smoothing="filter", ports=4, slots=8192),
+    "pusch273_1rx_none": dict(smoothing="none", ports=1, slots=1024),
+}
+
+
+def _cpu_worker(args):
+    """Oracle (CPU port of the reference algorithm) on one slot's ports, repeated; returns items done."""
+    case, n_ports, reps, seed = args
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import ce_oracle as O
+    from srsran_ce_pytorch_amd import synth as S
+
+    b = S.build_case(dict(case, seed=seed), n_ports)
+    for _ in range(2):                                                  # untimed warm-up (page faults, caches)
+        for r in range(n_ports):
+            O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for r in range(n_ports):
+            O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+    return reps * n_ports, time.perf_counter() - t0
+
+
+def cpu_baseline(case, n_ports, target_core_seconds=20.0):
+    """Bounded sample of the same workload on the host cores (fork happens BEFORE any GPU init)."""
+    import multiprocessing as mp
+
+    cores = min(16, len(os.sched_getaffinity(0)))
+    n1, t1 = _cpu_worker((case, n_ports, 3, 999))                 # per-item estimate on one core
+    per_item = t1 / n1
+    reps = max(1, int(target_core_seconds / cores / (per_item * n_ports)))
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(case, n_ports, reps, 1000 + i) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    items = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    slots = items / n_ports
+    return dict(value=slots / busy, unit="slots/s", cores=cores, kind="port",
+                sample=f"{int(slots)} slots x {n_ports} ports of the same 273-PRB workload through oracle/ce_oracle.py "
+                       f"(numpy port of ce_rule_tensorized), {cores} worker processes, {busy:.1f} s busy / {wall:.1f} s wall; "
+                       f"{per_item * 1e3:.2f} ms per slot-port on one core")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pusch273_4rx_filter", choices=sorted(WORKLOADS))
+    ap.add_argument("--slots", type=int, default=None, help="slots per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    from srsran_ce_pytorch_amd import synth as S
+
+    wl = WORKLOADS[args.workload]
+    n_slots = args.slots or wl["slots"]
+    n_ports = wl["ports"]
+    case = S.bench_case(wl["smoothing"], 1, seed=1234 + rank)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(case, n_ports)                           # before any GPU initialisation (forks)
+
+    import torch
+    import torch.distributed as dist
+    from srsran_ce_pytorch_amd import estimator as E
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    hop1, hop2, cfg = S.numpy_hops(case)
+    plan = E.make_plan(hop1, hop2, cfg, case["beta"], 1, case["n_prb_grid"], case["n_sym"], dev)
+    rx, pilots = S.torch_inputs(case, n_slots, n_ports, dev, seed=1234 + rank)
+    out = E.estimate_with_plan(plan, rx, pilots)                    # allocates the outputs once
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        E.estimate_with_plan(plan, rx, pilots, out)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                                    # same stream the kernel is launched on
+    for _ in range(args.steps):
+        E.estimate_with_plan(plan, rx, pilots, out)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # measurement only, not data path
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    # sanity: the batch really was estimated (finite outputs, CFO in the generated range)
+    assert bool(torch.isfinite(out[1]).all()) and bool(torch.isfinite(out[0][-1, -1].real).all())
+
+    bytes_per_slot = n_ports * plan.alg_bytes_per_item + plan.pilot_bytes_per_slot
+    bytes_per_launch = n_slots * bytes_per_slot
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    value = world * n_slots * args.steps / elapsed
+    line = {
+        "metric": "slots/sec (273-PRB PUSCH, 4 Rx)" if n_ports == 4 else f"slots/sec (273-PRB PUSCH, {n_ports} Rx)",
+        "value": value, "unit": "slots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "n_prb": 273, "n_sc": plan.n_sc, "n_sym": plan.n_sym, "dmrs_symbols": [2, 11],
+                   "layers": 1, "rx_ports": n_ports, "smoothing": wl["smoothing"], "slots_per_gpu": n_slots,
+                   "global_slots": world * n_slots, "rx_layout": "[slot][port][sym][sc]", "parallelism": f"slot-shard x{world}, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "ce_estimate_kernel<1,1>", "kernel_ms": kernel_ms,
+                     "alg_bytes_per_slot": bytes_per_slot, "alg_bytes_per_launch": bytes_per_launch},
+    }
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

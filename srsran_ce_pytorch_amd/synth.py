@@ -134,3 +134,67 @@ def config1_case(seed: int = 7) -> Dict[str, Any]:
     """BASELINE.json configs[0]: 25 PRB inside the 52-PRB grid of the srsRAN vectors, one DM-RS
     symbol, LS only (no smoothing); the CFO path returns "not estimated"."""
     return case_spec("cfg1_25prb_1dmrs_none", 52, [hop_spec([2], 10, 25)], smoothing="none", scs=15e3, seed=seed)
+
+
+# --------------------------------------------------------------------------------------------
+# On-device generator for the bench (same signal model, torch ops, inputs born in HBM)
+# --------------------------------------------------------------------------------------------
+def torch_inputs(case: Dict[str, Any], n_slots: int, n_ports: int, device, seed: int, chunk: int = 256):
+    """Returns ``(rx, pilots)``: ``rx`` is a ``[slots, ports, n_sym, n_sc]`` complex64 buffer viewed as
+    ``[slots, ports, n_sc, n_sym]`` (subcarrier-contiguous: the layout the kernel's pilot loads
+    coalesce on), ``pilots`` is ``[slots, n_re, n_dmrs_total, L]`` (one DM-RS sequence per slot, shared
+    by its Rx ports).  AWGN on every RE; pilots REs carry beta*H*pilot*CFO-ramp."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    n_sc, n_sym, L = 12 * case["n_prb_grid"], case["n_sym"], case["n_layers"]
+    scs, beta = case["scs"], case["beta"]
+    hops = [_hop_arrays(case, h) for h in case["hops"]]
+    cp_ms = normal_cp_ms(scs)
+    cpd = cp_ms * scs / 1000.0
+    sst = torch.as_tensor(np.cumsum(np.concatenate([[cpd[0]], cpd[1:14] + 1.0])), device=device, dtype=torch.float32)
+    n_re = int(hops[0].nPRBs * hops[0].DMRSREmask[:, 0].sum())
+    n_dmrs_tot = sum(len(h["dmrs_symbols"]) for h in case["hops"])
+
+    k = torch.randint(0, 4, (n_slots, n_re, n_dmrs_tot, (L + 1) // 2), generator=g, device=device)
+    base = torch.polar(torch.ones((), device=device), (math.pi / 4 + (math.pi / 2) * k).float())
+    occ = torch.where(torch.arange(n_re, device=device) % 2 == 0, 1.0, -1.0)[None, :, None]
+    pilots = torch.empty((n_slots, n_re, n_dmrs_tot, L), dtype=torch.complex64, device=device)
+    for l in range(L):
+        pilots[..., l] = base[..., l // 2] * (occ if l % 2 else 1.0)
+
+    rx = torch.empty((n_slots, n_ports, n_sym, n_sc), dtype=torch.complex64, device=device)
+    f_sc = torch.arange(n_sc, device=device, dtype=torch.float32) * scs
+    tap_delay = torch.tensor([0.0, 100e-9, 300e-9], device=device) + case["delay_ns"] * 1e-9
+    tap_amp = torch.tensor([1.0, 0.35, 0.2], device=device)
+    steer = torch.polar(tap_amp[:, None].expand(3, n_sc).contiguous(), -2 * math.pi * tap_delay[:, None] * f_sc[None, :])
+    sigma = math.sqrt(case["noise_var"] / 2)
+    for b0 in range(0, n_slots, chunk):
+        b1 = min(n_slots, b0 + chunk)
+        nb = b1 - b0
+        rxc = rx[b0:b1]
+        rxc.copy_(torch.view_as_complex(torch.randn((nb, n_ports, n_sym, n_sc, 2), generator=g, device=device) * sigma))
+        cfo = (case["cfo_hz"] * (0.5 + torch.rand((nb, n_ports), generator=g, device=device)) / scs) * \
+            torch.where(torch.rand((nb, n_ports), generator=g, device=device) < 0.5, 1.0, -1.0)
+        s_off = 0
+        for h, ha in zip(case["hops"], hops):
+            ph = torch.polar(torch.ones((), device=device), 2 * math.pi * torch.rand((nb, n_ports, L, 3), generator=g, device=device))
+            H = torch.einsum("brlt,tk->brlk", ph, steer)                       # [nb, R, L, n_sc]
+            for c in range(ha.DMRSREmask.shape[1]):
+                res = torch.as_tensor(np.flatnonzero(np.kron(ha.maskPRBs, ha.DMRSREmask[:, c])), device=device)
+                for si, sym in enumerate(h["dmrs_symbols"]):
+                    acc = torch.zeros((nb, n_ports, res.numel()), dtype=torch.complex64, device=device)
+                    for l in range(2 * c, min(L, 2 * c + 2)):
+                        acc += H[:, :, l, res] * pilots[b0:b1, None, :, s_off + si, l]
+                    ramp = torch.polar(torch.ones((), device=device), 2 * math.pi * sst[sym] * cfo)[:, :, None]
+                    rxc[:, :, sym, res] += beta * acc * ramp
+            s_off += len(h["dmrs_symbols"])
+    return rx.permute(0, 1, 3, 2), pilots
+
+
+def numpy_hops(case: Dict[str, Any]):
+    hops = [_hop_arrays(case, h) for h in case["hops"]]
+    cfg = SimpleNamespace(scs=case["scs"], CyclicPrefixDurations=normal_cp_ms(case["scs"]), Smoothing=case["smoothing"],
+                          CFOCompensate=case["cfo_compensate"])
+    return hops[0], (hops[1] if len(hops) > 1 else empty_hop_arrays()), cfg
