@@ -16,9 +16,11 @@ struct ce_plan {
   CeDevPlan host;
   CeDevPlan* dev_plan = nullptr;
   uint16_t* dev_re_idx = nullptr;
+  uint16_t* dev_ta_inv = nullptr;
   float2* dev_tw = nullptr;
   ce_plan_info info;
   int device = 0;
+  int grid_cap = 1;   // persistent grid: CUs x workgroups resident per CU
 };
 
 namespace {
@@ -110,6 +112,7 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
   }
 
   std::vector<uint16_t> re_idx;
+  std::vector<uint16_t> ta_inv((size_t)d->n_hops * CE_FFT_SIZE, 0xFFFFu);
   int n_re = -1, n_dmrs_total = 0, cfo_estimated = 0;
   uint8_t seen_sym[CE_MAX_SYMBOLS] = {0};
   for (int h = 0; h < d->n_hops; ++h) {
@@ -127,6 +130,7 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
       delete p;
       return fail(CE_ERR_INVALID, "The DM-RS mask should be the same for the two hops.");
     }
+    for (int i = 0; i < H.n_dmrs; ++i) P.sst_dmrs[h][i] = P.sst[H.dmrs_sym[i]];
     H.pil_sym0 = n_dmrs_total;
     n_dmrs_total += H.n_dmrs;
     H.has_cfo = H.n_dmrs >= 2;
@@ -147,11 +151,26 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
       delete p;
       return fail(CE_ERR_INVALID, "hop %d: sum(maskPRBs)=%d != nPRBs=%d (the reference's grid fill T:291-292 needs them equal)", h, n_active, hd.n_prbs);
     }
+    H.prb_start = hd.prb_start; H.n_prbs = hd.n_prbs;
+    H.contig = 1;
+    for (int q = 0; q < d->n_prb_grid; ++q)
+      if ((hd.mask_prbs[q] != 0) != (q >= hd.prb_start && q < hd.prb_start + hd.n_prbs)) H.contig = 0;
     for (int c = 0; c < n_cdm; ++c) {
       const unsigned m = hd.re_mask[c] & 0xFFFu;
       const int dpp = popcount12(m);
       if (dpp == 0) { delete p; return fail(CE_ERR_INVALID, "hop %d: DMRSREmask column %d is empty", h, c); }
       H.dpp[c] = dpp;
+      H.div_magic[c] = (uint32_t)(0x100000000ull / (unsigned)dpp) + 1u;
+      {
+        uint64_t pos = 0, ord = 0;
+        int j = 0;
+        for (int r = 0; r < 12; ++r) {
+          if (m >> r & 1) { pos |= (uint64_t)r << (4 * j); ord |= (uint64_t)j << (4 * r); ++j; }
+          else ord |= (uint64_t)15 << (4 * r);
+        }
+        H.pos_packed[c] = pos;
+        if (c == n_cdm - 1) H.ord_packed = ord;
+      }
       H.re_off[c] = (int)re_idx.size();
       // maskREs = kron(maskPRBs, DMRSREmask[:, c]) (T:572-576)
       for (int q = 0; q < d->n_prb_grid; ++q)
@@ -181,6 +200,18 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
         H.r_ord[c][r] = ord;
         H.alpha[c][r] = (float)(r - left_pos) / (float)(right_pos - left_pos);
       }
+    }
+    // time-alignment scatter uses the LAST CDM group's RE list for every layer (T:672-675)
+    {
+      H.ta_inv_off = h * CE_FFT_SIZE;
+      unsigned seen = 0;
+      for (int k = 0; k < n_re; ++k) {
+        const int pos = re_idx[H.re_off[n_cdm - 1] + k];
+        ta_inv[(size_t)h * CE_FFT_SIZE + pos] = (uint16_t)k;
+        seen |= 1u << (pos & 15);
+      }
+      for (int r = 0; r < 16; ++r)
+        if (seen >> r & 1) { H.ta_res_packed |= (uint64_t)r << (4 * H.ta_nres); H.ta_res[H.ta_nres++] = r; }
     }
     // nSamples = nSyms + sum(CPDs(i0+1 .. i1)), CPDs = cp_ms * (scs/1000) (T:395-426, called with scs/1000 at T:599)
     if (H.has_cfo) {
@@ -213,12 +244,43 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
     P.n_pils = n_active > 1 ? ((int)rc.size() / 2 < 12 ? (int)rc.size() / 2 : 12) : dpp0;  // T:644-647
     if (P.n_pils > n_re || P.n_pils < 1) { delete p; return fail(CE_ERR_UNSUPPORTED, "n_pils=%d vs n_re=%d", P.n_pils, n_re); }
     P.ext_len = n_re + 2 * P.n_pils;
-    P.filt_lpp = CE_FFT_SIZE / P.ext_len;
-    if (P.filt_lpp < 1) { delete p; return fail(CE_ERR_UNSUPPORTED, "band of %d pilots too wide for the LDS scratch", n_re); }
-    if (P.filt_lpp > L) P.filt_lpp = L;
+    for (size_t i = 0; i < rc.size(); ++i) P.rcz[i + CE_CONV_C - 1] = rc[i];
+    {
+      const double n = (double)P.n_pils;
+      double sxx = 0.0;
+      for (int i = 0; i < P.n_pils; ++i) sxx += (double)i * (double)i;
+      P.vp_mx = (n - 1.0) / 2.0;
+      P.vp_inv_n = 1.0 / n;
+      P.vp_inv_denom = P.n_pils > 1 ? 1.0 / (sxx - n * P.vp_mx * P.vp_mx) : 0.0;
+    }
+    P.filt_windowed = (n_re <= (CE_THREADS - 64) * CE_CONV_C && P.n_pils <= 12 && P.n_pils <= rc.size() / 2 + CE_CONV_C) ? 1 : 0;
   }
 
-  const CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad);
+  // LDS scratch: TA residue blocks | virtual-pilot-extended band for the RC FIR | writer's H chunk
+  {
+    int need = 0;
+    for (int h = 0; h < d->n_hops; ++h) need = P.hop[h].ta_nres * CE_TA_ROW * 8 > need ? P.hop[h].ta_nres * CE_TA_ROW * 8 : need;
+    if (d->smoothing == CE_SMOOTH_FILTER && P.ext_len * 8 > need) need = P.ext_len * 8;
+    if (P.n_hops * L * 256 * 8 > need) need = P.n_hops * L * 256 * 8;
+    P.scratch_bytes = need;
+    if (d->smoothing == CE_SMOOTH_FILTER) {
+      P.filt_lpp = need / (P.ext_len * 8);
+      if (P.filt_lpp > L) P.filt_lpp = L;
+    }
+    int lg = 8;
+    while (lg < 12 && P.n_hops * L * (2 << lg) * 8 <= need) ++lg;
+    P.wr_ch_log2 = lg;
+  }
+  // register path: every hop has the same 1 or 2 DM-RS symbols, one CDM group, band fits CE_KPT per thread
+  P.reg_nd = 0;
+  if (n_cdm == 1 && n_re <= CE_KPT * CE_THREADS) {
+    const int nd = P.hop[0].n_dmrs;
+    bool same = nd <= 2;
+    for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
+    if (same) P.reg_nd = nd;
+  }
+
+  const CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
   if (lay.total > 160 * 1024) { delete p; return fail(CE_ERR_UNSUPPORTED, "plan needs %d B of LDS (> 160 KiB)", lay.total); }
 
   ce_plan_info& I = p->info;
@@ -238,10 +300,15 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
   if (e == hipSuccess) e = hipMalloc(&p->dev_plan, sizeof(CeDevPlan));
   if (e == hipSuccess) e = hipMalloc(&p->dev_re_idx, re_idx.size() * sizeof(uint16_t));
   if (e == hipSuccess) e = hipMalloc(&p->dev_tw, tw.size() * sizeof(float2));
+  if (e == hipSuccess) e = hipMalloc(&p->dev_ta_inv, ta_inv.size() * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMemcpy(p->dev_ta_inv, ta_inv.data(), ta_inv.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->dev_plan, &P, sizeof(CeDevPlan), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->dev_re_idx, re_idx.data(), re_idx.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->dev_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = (hipError_t)ce_prepare_kernel(L, P.n_hops, lay.total);
+  int blocks_per_cu = 1, n_cu = 1;
+  if (e == hipSuccess) e = (hipError_t)ce_prepare_kernel(L, P.n_hops, P.reg_nd, lay.total, &blocks_per_cu);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device);
+  p->grid_cap = blocks_per_cu * n_cu;
   if (e != hipSuccess) {
     fail(CE_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
     ce_plan_destroy(p);
@@ -256,6 +323,7 @@ void ce_plan_destroy(ce_plan* p) {
   if (p->dev_plan) (void)hipFree(p->dev_plan);
   if (p->dev_re_idx) (void)hipFree(p->dev_re_idx);
   if (p->dev_tw) (void)hipFree(p->dev_tw);
+  if (p->dev_ta_inv) (void)hipFree(p->dev_ta_inv);
   delete p;
 }
 
@@ -274,6 +342,8 @@ static int check_batch(const ce_plan* plan, const void* rx, const int64_t* rs, c
   if (n_slots * n_ports > 0x7FFFFFFFll) return fail(CE_ERR_UNSUPPORTED, "more than 2^31-1 work items in one launch");
   for (int i = 0; i < 4; ++i)
     if (rs[i] < 0 || ps[i] < 0) return fail(CE_ERR_INVALID, "negative strides are not supported");
+  if ((plan->info.n_sc - 1) * rs[2] >= 0x7FFFFFFFll || (int64_t)(plan->info.n_re - 1) * ps[1] >= 0x7FFFFFFFll)
+    return fail(CE_ERR_UNSUPPORTED, "subcarrier / pilot strides too large for 32-bit in-item offsets");
   a->rx = (const float2*)rx; a->rs_b = rs[0]; a->rs_r = rs[1]; a->rs_sc = rs[2]; a->rs_sym = rs[3];
   a->pil = (const float2*)pilots; a->ps_b = ps[0]; a->ps_re = ps[1]; a->ps_sym = ps[2]; a->ps_l = ps[3];
   a->out = (float2*)ch_est; a->noise = noise; a->rsrp = rsrp; a->epre = epre; a->ta = ta; a->cfo = cfo;
@@ -288,7 +358,7 @@ int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_stri
   int rc = check_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, &a);
   if (rc != CE_OK) return rc;
   if (a.n_items == 0) return CE_OK;
-  int e = ce_launch(plan->host, plan->dev_plan, plan->dev_re_idx, plan->dev_tw, a, plan->info.lds_bytes, (hipStream_t)stream);
+  int e = ce_launch(plan->host, plan->dev_plan, plan->dev_re_idx, plan->dev_ta_inv, plan->dev_tw, a, plan->info.lds_bytes, plan->grid_cap, (hipStream_t)stream);
   if (e != 0) return fail(CE_ERR_HIP, "kernel launch failed: %s", e > 0 ? hipGetErrorString((hipError_t)e) : "no kernel for this (layers, hops)");
   return CE_OK;
 }

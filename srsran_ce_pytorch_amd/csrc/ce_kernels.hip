@@ -2,13 +2,16 @@
 // slot x Rx-port work item; everything between the received grid and the channel grid stays
 // in LDS/registers, the (n_sc, n_sym, L) output block is written once with 16-byte stores.
 //
-// Stage map (reference: src/ce_rule_tensorized.py, "T"):
-//   cfo_pass        S4  T:357-426   inner products of the first two DM-RS symbols -> CFO per hop
-//   ls_pass         S1-S3,S5 T:571-613  pilot gather, EPRE, LS (x conj(pilot)), de-rotation, DM-RS average
+// Stage map (reference: src/ce_rule_tensorized.py, "T"), per hop:
+//   load            S1  T:571-581   pilot REs of the DM-RS symbols (+ pilots) -> registers (register path)
+//   cfo             S4  T:357-426   inner products of the first two DM-RS symbols -> CFO of the hop
+//   ls              S2,S3,S5 T:584-613  EPRE, LS (x conj(pilot)), de-rotation, DM-RS average -> P in LDS
 //   despread        S6  T:620-628
 //   smooth_*        S7  T:633-668   mean | virtual pilots (T:69-140) + RC FIR (T:459-493)
-//   time_alignment  S8  T:670-698   4096-point inverse FFT in LDS, arg-max over +-144 bins
-//   residual_pass   S9,S11 T:700-730 reconstructed pilots, noise, RSRP
+//   time_alignment  S8  T:670-698   pruned 4096-point inverse DFT (3 radix-16 passes, only the residues
+//                                   mod 16 that carry pilots, only the 288 examined bins), arg-max
+//   residual        S9,S11 T:700-730 reconstructed pilots, noise, RSRP
+// then once per item:
 //   write_grid      S10 + epilogue T:237-354, T:921-929  linear interpolation, symbol replicate, CFO ramp
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -20,7 +23,36 @@ namespace {
 
 constexpr int NT = CE_THREADS;
 constexpr int NW = NT / 64;
-constexpr double kTwoPi = 6.283185307179586476925286766559;
+constexpr int KPT = CE_KPT;
+constexpr double kInvPi = 0.31830988618379067153776752674503;
+
+#ifndef CE_ABLATE
+#define CE_ABLATE 0   // timing experiments only (tools/ablate.py): 1 TA, 2 smoothing, 4 residual, 8 writer, 16 CFO, 32 input loads
+#endif
+#ifndef CE_MIN_WAVES
+#define CE_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
+#endif
+#ifndef CE_PERSIST
+#define CE_PERSIST 0      // 1: persistent workgroups that prefetch the next item's pilots before writing
+#endif
+#ifndef CE_STORE_WINDOW
+#define CE_STORE_WINDOW 0 // >0: a wave keeps at most this many grid stores in flight (s_waitcnt vmcnt)
+#endif
+#ifndef CE_NT_STORE
+#define CE_NT_STORE 0
+#endif
+
+#if defined(CE_STAMPS)
+// diagnostic build only (tools/stamps.py): per-stage wall-clock stamps of thread 0, written to a buffer
+// nothing else reads; never compiled into the shipped library
+__device__ unsigned long long* g_ce_stamps;
+#define STAMP(i)                                                      \
+  do {                                                                \
+    if (threadIdx.x == 0) g_ce_stamps[item * 16 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -31,10 +63,53 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CE_STR2(x) #x
+#define CE_STR(x) CE_STR2(x)
+__device__ __forceinline__ void store_f4(float4* p, float4 v) {
+#if CE_NT_STORE
+  __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+#else
+  *p = v;
+#endif
+#if CE_STORE_WINDOW > 0
+  // flow control: a deep per-CU store queue is what other workgroups' pilot loads wait behind
+  asm volatile("s_waitcnt vmcnt(" CE_STR(CE_STORE_WINDOW) ")" ::: "memory");
+#endif
+}
+
+// Compiler fence on a register value (no instruction).  Used after the CFO stage so its 14 pilot
+// products are not kept alive (56 VGPRs) for re-use by the LS stage across two barriers.
+__device__ __forceinline__ void pin(float2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+
+// sin(pi x), cos(pi x) of a float64 argument, to float32 accuracy: float32 sincospi of the rounded
+// argument plus a first-order correction for the rounding residue.  (ocml's float64 sincospi parks
+// ~70 VGPRs of polynomial constants, which would cost the whole kernel a wave of occupancy.)
+__device__ __forceinline__ void sincospi_f64arg(double x, float* sn, float* cs) {
+  const float hi = (float)x;
+  const float lo = (float)(x - (double)hi) * 3.14159265358979323846f;
+  float sh, ch;
+  sincospif(hi, &sh, &ch);
+  *sn = fmaf(lo, ch, sh);
+  *cs = fmaf(-lo, sh, ch);
+}
+
+// Cross-lane moves on the DPP path (VALU) instead of ds_bpermute (LDS crossbar, ~100 cycles a hop):
+// quad swaps, half-row / row mirrors, then row_bcast15 / row_bcast31 -- lane 63 ends up with the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {  // every lane returns the wave total
+  v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_f64<0x140, 0xF>(v);  // row_mirror
+  v += dpp_f64<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
+  v += dpp_f64<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // Sum N per-thread doubles over the workgroup; every thread receives the totals.
@@ -57,258 +132,388 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* red) {
   __syncthreads();
 }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xF, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {  // every lane returns the wave max
+  v = umax64(v, dpp_u64<0xB1, 0xF>(v));
+  v = umax64(v, dpp_u64<0x4E, 0xF>(v));
+  v = umax64(v, dpp_u64<0x141, 0xF>(v));
+  v = umax64(v, dpp_u64<0x140, 0xF>(v));
+  v = umax64(v, dpp_u64<0x142, 0xA>(v));
+  v = umax64(v, dpp_u64<0x143, 0xC>(v));
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// inverse (positive-exponent) radix-4 butterfly, natural order in and out
+__device__ __forceinline__ void r4inv(float2& a0, float2& a1, float2& a2, float2& a3) {
+  const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
+  const float2 jd = make_float2(-d13.y, d13.x);  // +j (a1 - a3)
+  a0 = cadd(s02, s13);
+  a1 = cadd(d02, jd);
+  a2 = csub(s02, s13);
+  a3 = csub(d02, jd);
+}
+
+// X[c] = sum_b v[b] exp(+j 2 pi b c / 16), in registers (radix-4 x radix-4), natural order
+__device__ __forceinline__ void idft16(float2 (&v)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
-}
-
-__device__ __forceinline__ int digit_reverse4_12(int n) {  // base-4 digit reversal of a 12-bit index
-  int r = 0;
+  for (int j = 0; j < 4; ++j) r4inv(v[j], v[j + 4], v[j + 8], v[j + 12]);  // v[j+4m] = A_j[m]
+  // B_j[m] = A_j[m] * W16^(j m)
+  v[1 + 4] = cmul(v[1 + 4], make_float2(C1, S1));      // j=1,m=1: W^1
+  v[1 + 8] = cmul(v[1 + 8], make_float2(R2, R2));      // j=1,m=2: W^2
+  v[1 + 12] = cmul(v[1 + 12], make_float2(S1, C1));    // j=1,m=3: W^3
+  v[2 + 4] = cmul(v[2 + 4], make_float2(R2, R2));      // j=2,m=1: W^2
+  v[2 + 8] = make_float2(-v[2 + 8].y, v[2 + 8].x);     // j=2,m=2: W^4 = +j
+  v[2 + 12] = cmul(v[2 + 12], make_float2(-R2, R2));   // j=2,m=3: W^6
+  v[3 + 4] = cmul(v[3 + 4], make_float2(S1, C1));      // j=3,m=1: W^3
+  v[3 + 8] = cmul(v[3 + 8], make_float2(-R2, R2));     // j=3,m=2: W^6
+  v[3 + 12] = cmul(v[3 + 12], make_float2(-C1, -S1));  // j=3,m=3: W^9
+  // X[m + 4n] = sum_j B_j[m] W4^(j n): radix-4 over j for each m; B_j[m] sits at v[j + 4m]
+  float2 o[16];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    r = (r << 2) | (n & 3);
-    n >>= 2;
+  for (int m = 0; m < 4; ++m) {
+    float2 b0 = v[4 * m], b1 = v[4 * m + 1], b2 = v[4 * m + 2], b3 = v[4 * m + 3];
+    r4inv(b0, b1, b2, b3);
+    o[m] = b0;
+    o[m + 4] = b1;
+    o[m + 8] = b2;
+    o[m + 12] = b3;
   }
-  return r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = o[i];
 }
 
-// In-place radix-4 decimation-in-frequency inverse FFT of 4096 complex64 values in LDS.
-// Natural-order input; bin n ends up at digit_reverse4_12(n).  No 1/N scale (arg-max only).
-__device__ void ifft4096_lds(float2* x, const float2* __restrict__ tw) {
-#pragma unroll 1
-  for (int s = 0; s < 6; ++s) {
-    const int span = 1024 >> (2 * s);
-    const int tws = 1 << (2 * s);
-    for (int b = threadIdx.x; b < 1024; b += NT) {
-      const int i = b & (span - 1);
-      const int base = ((b - i) << 2) + i;
-      float2 a0 = x[base], a1 = x[base + span], a2 = x[base + 2 * span], a3 = x[base + 3 * span];
-      float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
-      float2 jd13 = make_float2(-d13.y, d13.x);  // +j * (a1 - a3)
-      float2 y0 = cadd(s02, s13), y2 = csub(s02, s13), y1 = cadd(d02, jd13), y3 = csub(d02, jd13);
-      if (span > 1) {
-        const float2 w1 = tw[i * tws], w2 = tw[2 * i * tws], w3 = tw[3 * i * tws];
-        y1 = cmul(y1, w1);
-        y2 = cmul(y2, w2);
-        y3 = cmul(y3, w3);
-      }
-      x[base] = y0;
-      x[base + span] = y1;
-      x[base + 2 * span] = y2;
-      x[base + 3 * span] = y3;
-    }
-    __syncthreads();
-  }
-}
-
-struct Ctx {
-  const CeDevPlan* plan;
-  const uint16_t* re_idx;
-  const float2* rx;   // item base
-  const float2* pil;  // slot base
-  int64_t rs_sc, rs_sym, ps_re, ps_sym, ps_l;
-};
-
-// One 16-lane group per (layer, band edge): straight-line fit of modulus and unwrapped phase of
-// the n_pils pilots next to the edge, extrapolated n_pils positions outwards (T:69-140, T:35-66).
-__device__ void virtual_pilots(const float2* Pl, int n_re, int n_pils, bool tail, float2* ext_l, int j) {
+// One 16-lane group per band edge: straight-line fit of modulus and unwrapped phase of the n_pils pilots
+// next to the edge, extrapolated n_pils positions outwards (T:69-140, T:35-66).  `out(e)` receives the
+// virtual pilot at distance e+1 from the band (e = 0 is adjacent to the first / last real pilot).
+template <typename Out>
+__device__ __forceinline__ void virtual_pilots(const float2* Pl, int n_re, int n_pils, bool tail, int j,
+                                               double mx, double inv_n, double inv_denom, Out out) {
   const double PI = 3.14159265358979323846;
   float2 v = make_float2(0.f, 0.f);
   if (j < n_pils) v = tail ? Pl[n_re - 1 - j] : Pl[j];
-  double amp = (double)hypotf(v.x, v.y);
-  double ang = (double)atan2f(v.y, v.x);
+  const double amp = (double)hypotf(v.x, v.y);
+  const double ang = (double)atan2f(v.y, v.x);
   double outr, outi;
   if (n_pils == 1) {  // T:95-101
-    double sn, cs;
-    sincos(ang, &sn, &cs);
-    outr = amp * cs;
-    outi = amp * sn;
+    float sn, cs;
+    sincospi_f64arg(ang * kInvPi, &sn, &cs);
+    outr = amp * (double)cs;
+    outi = amp * (double)sn;
   } else {
     // unwrap: per-gap correction then inclusive prefix sum over the 16-lane group
-    double prev = __shfl_up(ang, 1, 16);
+    const double prev = __shfl_up(ang, 1, 16);
     double corr = 0.0;
     if (j >= 1 && j < n_pils) {
-      double dd = ang - prev;
-      double ddmod = fmod(dd + PI, 2.0 * PI);
-      if (ddmod < 0.0) ddmod += 2.0 * PI;  // torch.remainder: result has the divisor's sign
+      const double dd = ang - prev;
+      const double t = dd + PI;
+      double ddmod = t - 2.0 * PI * floor(t * (0.5 * kInvPi));  // remainder(dd + pi, 2 pi) in [0, 2 pi)
       ddmod -= PI;
       if (ddmod == -PI && dd > 0.0) ddmod += 2.0 * PI;
       corr = fabs(dd) < PI ? 0.0 : ddmod - dd;
     }
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
-      double t = __shfl_up(corr, o, 16);
+      const double t = __shfl_up(corr, o, 16);
       if (j >= o) corr += t;
     }
-    double ph = ang + corr;
+    const double ph = ang + corr;
+    const bool in = j < n_pils;
     const double x = (double)j;
-    double sx = j < n_pils ? x : 0.0, sxx = j < n_pils ? x * x : 0.0;
-    double sa = j < n_pils ? amp : 0.0, sxa = j < n_pils ? x * amp : 0.0;
-    double sp = j < n_pils ? ph : 0.0, sxp = j < n_pils ? x * ph : 0.0;
+    double sa = in ? amp : 0.0, sxa = in ? x * amp : 0.0, sp = in ? ph : 0.0, sxp = in ? x * ph : 0.0;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
-      sx += __shfl_xor(sx, o, 16);
-      sxx += __shfl_xor(sxx, o, 16);
       sa += __shfl_xor(sa, o, 16);
       sxa += __shfl_xor(sxa, o, 16);
       sp += __shfl_xor(sp, o, 16);
       sxp += __shfl_xor(sxp, o, 16);
     }
     const double n = (double)n_pils;
-    const double mx = sx / n, denom = sxx - n * mx * mx;
-    const double ma = sa / n, mp = sp / n;
-    const double a_amp = (sxa - n * mx * ma) / denom, b_amp = ma - a_amp * mx;
-    const double a_ph = (sxp - n * mx * mp) / denom, b_ph = mp - a_ph * mx;
+    const double ma = sa * inv_n, mp = sp * inv_n;
+    const double a_amp = (sxa - n * mx * ma) * inv_denom, b_amp = ma - a_amp * mx;
+    const double a_ph = (sxp - n * mx * mp) * inv_denom, b_ph = mp - a_ph * mx;
     const double k = (double)(j - n_pils);  // positions -nV .. -1
     const double va = a_amp * k + b_amp, vp = a_ph * k + b_ph;
-    double sn, cs;
-    sincos(vp, &sn, &cs);
-    outr = va * cs;
-    outi = va * sn;
+    float sn, cs;
+    sincospi_f64arg(vp * kInvPi, &sn, &cs);
+    outr = va * (double)cs;
+    outi = va * (double)sn;
   }
-  if (j < n_pils) {
-    // head: ext[j] (position j - nV); tail: flipped, ext[nP + n_re + (nV-1-j)]
-    const int idx = tail ? (n_pils + n_re + (n_pils - 1 - j)) : j;
-    ext_l[idx] = make_float2((float)outr, (float)outi);
-  }
+  if (j < n_pils) out(n_pils - 1 - j, make_float2((float)outr, (float)outi));  // lane j sits at distance n_pils - j
 }
 
-template <int L, int NH>
-__global__ __launch_bounds__(NT) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
+// Workgroup index -> work item.  Workgroups b, b+8, b+16, .. share an XCD (and its L2), so the Rx ports of one
+// slot -- which read the same DM-RS symbols -- are dealt to indices 8 apart.  Placement only affects speed.
+#ifndef CE_XCD_MAP
+#define CE_XCD_MAP 1
+#endif
+__device__ __forceinline__ int64_t item_of(int64_t b, int n_ports, int64_t n_items) {
+  if (!CE_XCD_MAP) return b;
+  const int64_t per = 8 * (int64_t)n_ports, g = b / per;
+  if ((g + 1) * per > n_items) return b;  // ragged tail: identity
+  const int j = (int)(b - g * per);
+  return (g * 8 + (j & 7)) * n_ports + (j >> 3);
+}
+
+// subcarrier of pilot k of CDM group c: computed for a contiguous allocation, looked up otherwise (T:572-576)
+__device__ __forceinline__ int pilot_sc(const CeDevHop& hp, const uint16_t* __restrict__ re_idx, int c, int k) {
+  if (hp.contig) {
+    const int q = (int)__umulhi((unsigned)k, hp.div_magic[c]);
+    const int j = k - q * hp.dpp[c];
+    return 12 * (hp.prb_start + q) + (int)((hp.pos_packed[c] >> (4 * j)) & 15u);
+  }
+  return re_idx[hp.re_off[c] + k];
+}
+
+template <int L, int NH, int ND>
+__global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
                                                          const uint16_t* __restrict__ re_idx,
+                                                         const uint16_t* __restrict__ ta_inv,
                                                          const float2* __restrict__ tw, CeKernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int64_t item = blockIdx.x;
-  if (item >= a.n_items) return;
-  const int64_t slot = item / a.n_ports;
-  const int port = (int)(item - slot * a.n_ports);
+  constexpr bool REG = ND > 0;
+  constexpr int NC = (L + 1) / 2;
+  const int tid0 = threadIdx.x;
+  int tid = tid0;
 
-  const int n_re = plan->n_re, n_re_pad = plan->n_re_pad, n_cdm = plan->n_cdm;
-  const CeLdsLayout lay = ce_lds_layout(NH, L, n_re_pad);
+  const int n_re = plan->n_re, n_re_pad = plan->n_re_pad;
+  const CeLdsLayout lay = ce_lds_layout(NH, L, n_re_pad, plan->scratch_bytes);
   float2* P = reinterpret_cast<float2*>(smem + lay.off_p);              // [NH][L][n_re_pad]
-  float2* scratch = reinterpret_cast<float2*>(smem + lay.off_scratch);   // 4096 complex
+  float2* scratch = reinterpret_cast<float2*>(smem + lay.off_scratch);   // scratch_bytes
   double* red = reinterpret_cast<double*>(smem + lay.off_red);
-  float2* rot_final = reinterpret_cast<float2*>(smem + lay.off_rot);     // [16]
-  float2* rot_neg = rot_final + 16;                                      // [NH][16] exp(-j ph) at DM-RS symbols
-  float2* rot_pos = rot_neg + CE_MAX_HOPS * 16;                          // [NH][16] exp(+j ph)
+  float2* rot_final = reinterpret_cast<float2*>(smem + lay.off_rot);     // [16] exp(+j ph) of the final CFO
+  float2* rot_neg = rot_final + 16;                                      // [16] exp(-j ph) at the hop's DM-RS symbols
+  float2* rot_pos = rot_neg + 16;                                        // [16] exp(+j ph)
   float2* tab = reinterpret_cast<float2*>(smem + lay.off_tab);           // [NH][CDM][12] {alpha, bits(r_ord)}
-  double* misc = reinterpret_cast<double*>(smem + lay.off_misc);         // [0..1] cfo_hop, [2] cfo_final
+  double* misc = reinterpret_cast<double*>(smem + lay.off_misc);         // [0..1] cfo_hop
+  double* sst_l = misc + 4;                                              // [16] symbolStartTime
+  double* sst_dm = misc + 20;                                            // [2][14] ... at the hops' DM-RS symbols
+  float2* tw256 = reinterpret_cast<float2*>(smem + lay.off_tw);          // [256] W256^j = exp(+j 2 pi j / 256)
+  float2* tw16 = tw256 + 256;                                            // [16]  W4096^i
+  double* rcz = reinterpret_cast<double*>(smem + lay.off_rcz);           // zero-padded RC taps
 
-  const float2* rx = a.rx + slot * a.rs_b + port * a.rs_r;
-  const float2* pil = a.pil + slot * a.ps_b;
   const float beta_f = plan->beta_f;
   const bool cfo_comp = plan->cfo_comp != 0;
 
-  // interpolation tables -> LDS
+  // twiddles for the TA transform -> LDS (global loads issued now, consumed many barriers later)
+  for (int i = tid; i < 256 + 16; i += NT) tw256[i] = i < 256 ? tw[16 * i] : tw[i - 256];
+  for (int i = tid; i < CE_RCZ_LEN; i += NT) rcz[i] = plan->rcz[i];
+  if (tid < CE_MAX_SYMBOLS) sst_l[tid] = plan->sst[tid];
+  if (tid >= 64 && tid < 64 + CE_MAX_HOPS * CE_MAX_SYMBOLS) sst_dm[tid - 64] = (&plan->sst_dmrs[0][0])[tid - 64];
+  // interpolation tables -> LDS (first read after several barriers)
   for (int i = tid; i < NH * CE_MAX_CDM * 12; i += NT) {
     const int h = i / (CE_MAX_CDM * 12), c = (i / 12) % CE_MAX_CDM, r = i % 12;
     tab[i] = make_float2(plan->hop[h].alpha[c][r], __int_as_float(plan->hop[h].r_ord[c][r]));
   }
 
-  // ---------------------------------------------------------------- CFO per hop (S4)
+  // Register path: received pilot REs and DM-RS symbols of (item, hop), KPT per thread.  Hop 0 of the
+  // NEXT item is requested before the current item's grid is written, so the HBM latency of the only
+  // dependent global read hides behind ~367 KB of stores.
+  float2 xr[REG ? KPT * ND : 1];
+  float2 pr[REG ? KPT * ND * L : 1];
+  auto load_hop = [&](int64_t it, int h) {
+    if constexpr (REG) {
+      const CeDevHop& hp = plan->hop[h];
+      const int64_t sl = it / a.n_ports;
+      const float2* rx = a.rx + sl * a.rs_b + (it - sl * a.n_ports) * a.rs_r;
+      const float2* pil = a.pil + sl * a.ps_b;
 #pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    const CeDevHop& hp = plan->hop[h];
-    if (!hp.has_cfo) continue;  // uniform
-    double acc[2 * L];
+      for (int i = 0; i < KPT; ++i) {
+        const int k = tid + i * NT;
+        if (k < n_re && (CE_ABLATE & 32)) {  // timing experiment: no global reads at all
 #pragma unroll
-    for (int i = 0; i < 2 * L; ++i) acc[i] = 0.0;
-    const int64_t o0 = hp.dmrs_sym[0] * a.rs_sym, o1 = hp.dmrs_sym[1] * a.rs_sym;
-    const int64_t p0 = hp.pil_sym0 * a.ps_sym, p1 = (hp.pil_sym0 + 1) * a.ps_sym;
-    for (int k = tid; k < n_re; k += NT) {
+          for (int s = 0; s < ND; ++s) {
+            xr[i * ND + s] = make_float2(1.f + k * 1e-3f, 0.5f);
 #pragma unroll
-      for (int c = 0; c < (L + 1) / 2; ++c) {
-        const int64_t sc = re_idx[hp.re_off[c] + k];
-        const float2 x0 = rx[sc * a.rs_sc + o0], x1 = rx[sc * a.rs_sc + o1];
+            for (int l = 0; l < L; ++l) pr[(i * ND + s) * L + l] = make_float2(0.7071f, -0.7071f);
+          }
+        } else if (k < n_re) {
+          // uniform 64-bit base (SGPR pair) + 32-bit per-thread offset: one address VGPR per pilot RE
+          // instead of two per load (the host checks the offsets fit 32 bits)
+          const unsigned xo = (unsigned)pilot_sc(hp, re_idx, 0, k) * (unsigned)a.rs_sc;
+          const unsigned po = (unsigned)k * (unsigned)a.ps_re;
 #pragma unroll
-        for (int l = 2 * c; l < 2 * c + 2 && l < L; ++l) {
-          const float2 q0 = pil[k * a.ps_re + p0 + l * a.ps_l], q1 = pil[k * a.ps_re + p1 + l * a.ps_l];
-          const float2 r0 = cmul_conj(x0, q0), r1 = cmul_conj(x1, q1);
-          const float2 in = cmul_conj(r1, r0);  // conj(r0) * r1
-          acc[2 * l] += (double)in.x;
-          acc[2 * l + 1] += (double)in.y;
+          for (int s = 0; s < ND; ++s) {
+            const float2* rx_s = rx + hp.dmrs_sym[s] * a.rs_sym;
+            xr[i * ND + s] = rx_s[xo];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+              const float2* pil_sl = pil + (hp.pil_sym0 + s) * a.ps_sym + l * a.ps_l;
+              pr[(i * ND + s) * L + l] = pil_sl[po];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < ND; ++s) {
+            xr[i * ND + s] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int l = 0; l < L; ++l) pr[(i * ND + s) * L + l] = make_float2(0.f, 0.f);
+          }
         }
       }
     }
-    block_sum<2 * L>(acc, red);
-    if (tid == 0) {
-      double ang = 0.0;
-#pragma unroll
-      for (int l = 0; l + 1 < L; l += 2)  // CDM pairs are summed before the angle (T:410-413)
-        ang += (double)atan2f((float)(acc[2 * l + 1] + acc[2 * l + 3]), (float)(acc[2 * l] + acc[2 * l + 2]));
-      if (L & 1) ang += (double)atan2f((float)acc[2 * L - 1], (float)acc[2 * L - 2]);
-      misc[h] = ang / hp.two_pi_nsamples / plan->denom_cdm;
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {  // running mean over hops (T:605-609)
-    double cfo = 0.0;
-    bool have = false;
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-      if (plan->hop[h].has_cfo) {
-        cfo = have ? (cfo + misc[h]) / 2 : misc[h];
-        have = true;
-      }
-    misc[2] = cfo;
-  }
-  __syncthreads();
-  const bool apply_rot = cfo_comp && plan->cfo_estimated;
-  if (tid < 16) {
-    float2 r = make_float2(1.f, 0.f);
-    if (apply_rot && tid < CE_MAX_SYMBOLS) {
-      double sn, cs;
-      sincos(kTwoPi * plan->sst[tid] * misc[2], &sn, &cs);
-      r = make_float2((float)cs, (float)sn);
-    }
-    rot_final[tid] = r;
-  } else if (tid >= 64 && tid < 64 + NH * 16) {
-    const int h = (tid - 64) >> 4, s = (tid - 64) & 15;
-    const CeDevHop& hp = plan->hop[h];
-    float2 rn = make_float2(1.f, 0.f), rp = make_float2(1.f, 0.f);
-    if (cfo_comp && hp.has_cfo && s < hp.n_dmrs) {
-      double sn, cs;
-      sincos(kTwoPi * plan->sst[hp.dmrs_sym[s]] * misc[h], &sn, &cs);
-      rn = make_float2((float)cs, (float)(-sn));
-      rp = make_float2((float)cs, (float)sn);
-    }
-    rot_neg[h * 16 + s] = rn;
-    rot_pos[h * 16 + s] = rp;
-  }
-  __syncthreads();
+  };
+  if (blockIdx.x < a.n_items) load_hop(item_of(blockIdx.x, a.n_ports, a.n_items), 0);
 
+#if CE_PERSIST
+  // persistent workgroups: items blockIdx.x, blockIdx.x + gridDim.x, ...
+#pragma unroll 1
+  for (int64_t wg = blockIdx.x; wg < a.n_items; wg += gridDim.x) {
+  const int64_t item = item_of(wg, a.n_ports, a.n_items);
+#else
+  {
+  if (blockIdx.x >= a.n_items) return;
+  const int64_t item = item_of(blockIdx.x, a.n_ports, a.n_items);
+#endif
+  // Everything a stage derives from the thread index and the plan is loop-invariant; left alone, the
+  // compiler hoists all of it out of the item loop and keeps ~100 extra registers live across every
+  // stage.  An opaque copy of the thread index (and a memory barrier for the plan reads) keeps each
+  // stage's temporaries local to the stage.
+#if CE_PERSIST
+  tid = tid0;
+  asm volatile("" : "+v"(tid) : : "memory");
+#endif
+  const int64_t slot = item / a.n_ports;
+  const int port = (int)(item - slot * a.n_ports);
+  const float2* rx = a.rx + slot * a.rs_b + port * a.rs_r;
+  const float2* pil = a.pil + slot * a.ps_b;
   double tot_epre = 0.0, tot_noise = 0.0, tot_rsrp = 0.0, tot_ta = 0.0;
+  STAMP(0);
 
 #pragma unroll 1
   for (int h = 0; h < NH; ++h) {
     const CeDevHop& hp = plan->hop[h];
     float2* Ph = P + h * L * n_re_pad;
-    const int n_dmrs = hp.n_dmrs;
+    const int n_dmrs = REG ? ND : hp.n_dmrs;
     const float n_dmrs_f = (float)n_dmrs;
+    const bool has_cfo = REG ? (ND >= 2) : (hp.has_cfo != 0);
+    if (h > 0) load_hop(item, h);
 
-    // ------------------------------------------------------------ LS + DM-RS average (S1-S3, S5)
-    float epre_part = 0.f;
-    for (int k = tid; k < n_re; k += NT) {
+    STAMP(1);
+    // ------------------------------------------------------------ CFO of the hop (S4)
+    double cfo_hop = 0.0;
+    if (has_cfo && !(CE_ABLATE & 16)) {
+      double acc[2 * L];
 #pragma unroll
-      for (int c = 0; c < (L + 1) / 2; ++c) {
-        const int64_t sc = re_idx[hp.re_off[c] + k];
-        float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
-        for (int s = 0; s < n_dmrs; ++s) {
-          const float2 x = rx[sc * a.rs_sc + hp.dmrs_sym[s] * a.rs_sym];
-          epre_part += x.x * x.x + x.y * x.y;
-          const float2 rn = rot_neg[h * 16 + s];
-          const int64_t pb = k * a.ps_re + (hp.pil_sym0 + s) * a.ps_sym;
-          acc0 = cadd(acc0, cmul(cmul_conj(x, pil[pb + (2 * c) * a.ps_l]), rn));
-          if (2 * c + 1 < L) acc1 = cadd(acc1, cmul(cmul_conj(x, pil[pb + (2 * c + 1) * a.ps_l]), rn));
+      for (int i = 0; i < 2 * L; ++i) acc[i] = 0.0;
+      if constexpr (REG && ND >= 2) {
+        float part[2 * L];
+#pragma unroll
+        for (int i = 0; i < 2 * L; ++i) part[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+#pragma unroll
+          for (int l = 0; l < L; ++l) {
+            const float2 r0 = cmul_conj(xr[i * ND], pr[(i * ND) * L + l]);
+            const float2 r1 = cmul_conj(xr[i * ND + 1], pr[(i * ND + 1) * L + l]);
+            const float2 in = cmul_conj(r1, r0);  // conj(r0) * r1
+            part[2 * l] += in.x;
+            part[2 * l + 1] += in.y;
+          }
+          // keep the unrolled iterations sequential: otherwise all 14 products are formed first and the
+          // stage peaks at 2x the registers of the pilots it reads
+          if (i + 1 < KPT) asm volatile("" : "+v"(part[0]), "+v"(part[1]), "+v"(xr[(i + 1) * ND].x));
         }
-        Ph[(2 * c) * n_re_pad + k] = make_float2(acc0.x / beta_f / n_dmrs_f, acc0.y / beta_f / n_dmrs_f);
-        if (2 * c + 1 < L)
-          Ph[(2 * c + 1) * n_re_pad + k] = make_float2(acc1.x / beta_f / n_dmrs_f, acc1.y / beta_f / n_dmrs_f);
+#pragma unroll
+        for (int i = 0; i < 2 * L; ++i) acc[i] = (double)part[i];
+      } else if constexpr (!REG) {
+        const int64_t o0 = hp.dmrs_sym[0] * a.rs_sym, o1 = hp.dmrs_sym[1] * a.rs_sym;
+        const int64_t p0 = hp.pil_sym0 * a.ps_sym, p1 = (hp.pil_sym0 + 1) * a.ps_sym;
+        for (int k = tid; k < n_re; k += NT) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int64_t sc = pilot_sc(hp, re_idx, c, k);
+            const float2 x0 = rx[sc * a.rs_sc + o0], x1 = rx[sc * a.rs_sc + o1];
+#pragma unroll
+            for (int l = 2 * c; l < 2 * c + 2 && l < L; ++l) {
+              const float2 q0 = pil[k * a.ps_re + p0 + l * a.ps_l], q1 = pil[k * a.ps_re + p1 + l * a.ps_l];
+              const float2 r0 = cmul_conj(x0, q0), r1 = cmul_conj(x1, q1);
+              const float2 in = cmul_conj(r1, r0);
+              acc[2 * l] += (double)in.x;
+              acc[2 * l + 1] += (double)in.y;
+            }
+          }
+        }
+      }
+      block_sum<2 * L>(acc, red);
+      if (tid < 16) {  // every thread holds the totals: lanes 0..15 turn them into the hop's CFO and phasors
+        double ang = 0.0;
+#pragma unroll
+        for (int l = 0; l + 1 < L; l += 2)  // CDM pairs are summed before the angle (T:410-413)
+          ang += (double)atan2f((float)(acc[2 * l + 1] + acc[2 * l + 3]), (float)(acc[2 * l] + acc[2 * l + 2]));
+        if (L & 1) ang += (double)atan2f((float)acc[2 * L - 1], (float)acc[2 * L - 2]);
+        cfo_hop = ang / hp.two_pi_nsamples / plan->denom_cdm;
+        if (tid == 0) misc[h] = cfo_hop;
+      }
+    }
+    STAMP(2);
+    if constexpr (REG) {
+#pragma unroll
+      for (int i = 0; i < KPT * ND; ++i) pin(xr[i]);
+    }
+    if (tid < 16) {  // de-rotation / re-rotation phasors of the hop's DM-RS symbols (T:439-447, T:713-718)
+      float2 rn = make_float2(1.f, 0.f), rp = make_float2(1.f, 0.f);
+      if (cfo_comp && has_cfo && tid < n_dmrs && !(CE_ABLATE & 16)) {
+        float sn, cs;
+        sincospi_f64arg(2.0 * sst_dm[h * CE_MAX_SYMBOLS + tid] * cfo_hop, &sn, &cs);
+        rn = make_float2(cs, -sn);
+        rp = make_float2(cs, sn);
+      }
+      rot_neg[tid] = rn;
+      rot_pos[tid] = rp;
+    }
+    __syncthreads();
+
+    STAMP(3);
+    // ------------------------------------------------------------ EPRE, LS, DM-RS average (S2, S3, S5)
+    float epre_part = 0.f;
+    if constexpr (REG) {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const int k = tid + i * NT;
+        float2 acc[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) acc[l] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < ND; ++s) {
+          const float2 x = xr[i * ND + s];
+          epre_part += x.x * x.x + x.y * x.y;
+          const float2 rn = rot_neg[s];
+#pragma unroll
+          for (int l = 0; l < L; ++l) acc[l] = cadd(acc[l], cmul(cmul_conj(x, pr[(i * ND + s) * L + l]), rn));
+        }
+        if (k < n_re) {
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+            Ph[l * n_re_pad + k] = make_float2(acc[l].x / beta_f / n_dmrs_f, acc[l].y / beta_f / n_dmrs_f);
+        }
+      }
+    } else {
+      for (int k = tid; k < n_re; k += NT) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int64_t sc = pilot_sc(hp, re_idx, c, k);
+          float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+          for (int s = 0; s < n_dmrs; ++s) {
+            const float2 x = rx[sc * a.rs_sc + hp.dmrs_sym[s] * a.rs_sym];
+            epre_part += x.x * x.x + x.y * x.y;
+            const float2 rn = rot_neg[s];
+            const int64_t pb = k * a.ps_re + (hp.pil_sym0 + s) * a.ps_sym;
+            acc0 = cadd(acc0, cmul(cmul_conj(x, pil[pb + (2 * c) * a.ps_l]), rn));
+            if (2 * c + 1 < L) acc1 = cadd(acc1, cmul(cmul_conj(x, pil[pb + (2 * c + 1) * a.ps_l]), rn));
+          }
+          Ph[(2 * c) * n_re_pad + k] = make_float2(acc0.x / beta_f / n_dmrs_f, acc0.y / beta_f / n_dmrs_f);
+          if (2 * c + 1 < L)
+            Ph[(2 * c + 1) * n_re_pad + k] = make_float2(acc1.x / beta_f / n_dmrs_f, acc1.y / beta_f / n_dmrs_f);
+        }
       }
     }
     __syncthreads();
@@ -327,8 +532,10 @@ __global__ __launch_bounds__(NT) void ce_estimate_kernel(const CeDevPlan* __rest
       __syncthreads();
     }
 
+    STAMP(4);
     // ------------------------------------------------------------ frequency smoothing (S7)
-    if (plan->smoothing == CE_SMOOTH_MEAN) {
+    if (CE_ABLATE & 2) {
+    } else if (plan->smoothing == CE_SMOOTH_MEAN) {
       double m[2 * L];
 #pragma unroll
       for (int i = 0; i < 2 * L; ++i) m[i] = 0.0;
@@ -348,77 +555,245 @@ __global__ __launch_bounds__(NT) void ce_estimate_kernel(const CeDevPlan* __rest
       }
       __syncthreads();
     } else if (plan->smoothing == CE_SMOOTH_FILTER) {
-      const int n_pils = plan->n_pils, rc_len = plan->rc_len, ext_len = plan->ext_len, lpp = plan->filt_lpp;
+      const int n_pils = plan->n_pils, rc_len = plan->rc_len;
       const int pad = rc_len / 2;
+      const double vmx = plan->vp_mx, vin = plan->vp_inv_n, vid = plan->vp_inv_denom;
+      if (plan->filt_windowed) {
+        // Sliding-window FIR: conv(x, rc, "same") of [virtual head ; P ; virtual tail] cropped back to P
+        // (T:649-664).  Threads 0..NT-65 own CE_CONV_C consecutive outputs and accumulate the taps that hit
+        // real pilots (float64 MACs, T:477-490) while the last wave fits the virtual pilots; after one
+        // barrier the few threads whose window reaches past a band edge add the virtual-pilot taps.
+        constexpr int CV = CE_CONV_C, NCV = NT - 64;
+        float2* vpb = scratch;  // [2][16]: virtual pilot at distance e+1 beyond the head / tail edge
+        const int m0 = tid * CV;
+        const int nw = CV + 2 * pad;
 #pragma unroll 1
-      for (int l0 = 0; l0 < L; l0 += lpp) {
-        const int nl = min(lpp, L - l0);
-        // virtual pilots: one 16-lane group per (layer, edge)
-        if (tid < nl * 32) {
-          const int g = tid >> 4, j = tid & 15;
-          virtual_pilots(Ph + (l0 + (g >> 1)) * n_re_pad, n_re, n_pils, (g & 1) != 0, scratch + (g >> 1) * ext_len, j);
-        }
-        for (int i = tid; i < nl * n_re; i += NT) {
-          const int ll = i / n_re, k = i - ll * n_re;
-          scratch[ll * ext_len + n_pils + k] = Ph[(l0 + ll) * n_re_pad + k];
-        }
-        __syncthreads();
-        // conv(x, rc, "same") cropped by n_pils on both sides, float64 MACs (T:459-493, T:660-664)
-        for (int i = tid; i < nl * n_re; i += NT) {
-          const int ll = i / n_re, m = i - ll * n_re;
-          const float2* x = scratch + ll * ext_len;
-          double ar = 0.0, ai = 0.0;
-          for (int j = 0; j < rc_len; ++j) {
-            const int xi = m + n_pils + pad - j;
-            if (xi >= 0 && xi < ext_len) {
-              const float2 v = x[xi];
-              const double w = plan->rc[j];
-              ar += w * (double)v.x;
-              ai += w * (double)v.y;
+        for (int l = 0; l < L; ++l) {
+          float2* Pl = Ph + l * n_re_pad;
+          double ar[CV], ai[CV];
+#pragma unroll
+          for (int o = 0; o < CV; ++o) ar[o] = ai[o] = 0.0;
+          if (tid >= NCV) {
+            if (tid - NCV < 32) {
+              const int e = (tid - NCV) >> 4;
+              virtual_pilots(Pl, n_re, n_pils, e != 0, (tid - NCV) & 15, vmx, vin, vid,
+                             [&](int dist, float2 val) { vpb[e * 16 + dist] = val; });
+            }
+          } else if (m0 < n_re) {
+            for (int w = 0; w < nw; ++w) {
+              const int idx = m0 - pad + w;
+              if (idx >= 0 && idx < n_re) {
+                const float2 x = Pl[idx];
+                const double dx = (double)x.x, dy = (double)x.y;
+                const double* hz = rcz + (2 * pad + CV - 1 - w);  // taps for outputs o = 0..CV-1
+#pragma unroll
+                for (int o = 0; o < CV; ++o) {
+                  ar[o] += hz[o] * dx;
+                  ai[o] += hz[o] * dy;
+                }
+              }
             }
           }
-          Ph[(l0 + ll) * n_re_pad + m] = make_float2((float)ar, (float)ai);
+          __syncthreads();
+          if (tid < NCV && m0 < n_re) {
+            if (m0 - pad < 0 || m0 + CV - 1 + pad >= n_re) {
+              for (int w = 0; w < nw; ++w) {
+                const int idx = m0 - pad + w;
+                int vi = -1;
+                if (idx < 0 && -1 - idx < n_pils) vi = -1 - idx;                      // head, distance -idx
+                else if (idx >= n_re && idx - n_re < n_pils) vi = 16 + (idx - n_re);  // tail
+                if (vi >= 0) {
+                  const float2 x = vpb[vi];
+                  const double dx = (double)x.x, dy = (double)x.y;
+                  const double* hz = rcz + (2 * pad + CV - 1 - w);
+#pragma unroll
+                  for (int o = 0; o < CV; ++o) {
+                    ar[o] += hz[o] * dx;
+                    ai[o] += hz[o] * dy;
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for (int o = 0; o < CV; ++o)
+              if (m0 + o < n_re) Pl[m0 + o] = make_float2((float)ar[o], (float)ai[o]);
+          }
+          __syncthreads();
         }
-        __syncthreads();
+      } else {
+        // generic form (very wide bands): copy [virtual ; P ; virtual] to the scratch, one output per thread
+        const int ext_len = plan->ext_len, lpp = plan->filt_lpp;
+#pragma unroll 1
+        for (int l0 = 0; l0 < L; l0 += lpp) {
+          const int nl = min(lpp, L - l0);
+          if (tid < nl * 32) {
+            const int g = tid >> 4;
+            float2* ext = scratch + (g >> 1) * ext_len;
+            const bool tail = (g & 1) != 0;
+            virtual_pilots(Ph + (l0 + (g >> 1)) * n_re_pad, n_re, n_pils, tail, tid & 15, vmx, vin, vid,
+                           [&](int dist, float2 val) { ext[tail ? n_pils + n_re + dist : n_pils - 1 - dist] = val; });
+          }
+          for (int i = tid; i < nl * n_re; i += NT) {
+            const int ll = i / n_re, k = i - ll * n_re;
+            scratch[ll * ext_len + n_pils + k] = Ph[(l0 + ll) * n_re_pad + k];
+          }
+          __syncthreads();
+          for (int i = tid; i < nl * n_re; i += NT) {
+            const int ll = i / n_re, m = i - ll * n_re;
+            const float2* x = scratch + ll * ext_len;
+            double ar = 0.0, ai = 0.0;
+            for (int j = 0; j < rc_len; ++j) {
+              const int xi = m + n_pils + pad - j;
+              if (xi >= 0 && xi < ext_len) {
+                const float2 v = x[xi];
+                const double w = rcz[j + CE_CONV_C - 1];
+                ar += w * (double)v.x;
+                ai += w * (double)v.y;
+              }
+            }
+            Ph[(l0 + ll) * n_re_pad + m] = make_float2((float)ar, (float)ai);
+          }
+          __syncthreads();
+        }
       }
     }
 
-    // ------------------------------------------------------------ time alignment (S8)
+    STAMP(5);
+    // ------------------------------------------------------------ residual noise, RSRP (S9, S11)
     {
-      float pw0 = 0.f, pw1 = 0.f;  // bins tid and tid + NT of the 288 examined
-      const uint16_t* ta_idx = re_idx + hp.re_off[n_cdm - 1];  // LAST CDM group's mask for every layer (T:672-675)
-#pragma unroll 1
-      for (int l = 0; l < L; ++l) {
-        float4* s4 = reinterpret_cast<float4*>(scratch);
-        for (int i = tid; i < CE_FFT_SIZE / 2; i += NT) s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        for (int k = tid; k < n_re; k += NT) scratch[ta_idx[k]] = Ph[l * n_re_pad + k];
-        __syncthreads();
-        ifft4096_lds(scratch, tw);
-        {
-          const int n = tid < CE_TA_HALF ? tid : CE_FFT_SIZE - 2 * CE_TA_HALF + tid;
-          const float2 v = scratch[digit_reverse4_12(n)];
-          pw0 += v.x * v.x + v.y * v.y;
-          if (tid + NT < 2 * CE_TA_HALF) {
-            const int n1 = CE_FFT_SIZE - 2 * CE_TA_HALF + tid + NT;
-            const float2 v1 = scratch[digit_reverse4_12(n1)];
-            pw1 += v1.x * v1.x + v1.y * v1.y;
+      float noise_part = 0.f, rsrp_part = 0.f;
+      if constexpr (REG) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+          const int k = tid + i * NT;
+          if (k < n_re && !(CE_ABLATE & 4)) {
+            float2 hl[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+              hl[l] = Ph[l * n_re_pad + k];
+              rsrp_part += hl[l].x * hl[l].x + hl[l].y * hl[l].y;
+            }
+#pragma unroll
+            for (int s = 0; s < ND; ++s) {
+              const float2 rp = rot_pos[s];
+              float2 est = make_float2(0.f, 0.f);
+#pragma unroll
+              for (int l = 0; l < L; ++l) est = cadd(est, cmul(pr[(i * ND + s) * L + l], cmul(hl[l], rp)));
+              const float dr = xr[i * ND + s].x - beta_f * est.x, di = xr[i * ND + s].y - beta_f * est.y;
+              noise_part += dr * dr + di * di;
+            }
           }
         }
+      } else {
+        for (int k = tid; k < ((CE_ABLATE & 4) ? 0 : n_re); k += NT) {
+#pragma unroll
+          for (int l = 0; l < L; ++l) {
+            const float2 v = Ph[l * n_re_pad + k];
+            rsrp_part += v.x * v.x + v.y * v.y;
+          }
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int64_t sc = pilot_sc(hp, re_idx, c, k);
+            const float2 h0 = Ph[(2 * c) * n_re_pad + k];
+            const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * n_re_pad + k] : make_float2(0.f, 0.f);
+            for (int s = 0; s < n_dmrs; ++s) {
+              const float2 x = rx[sc * a.rs_sc + hp.dmrs_sym[s] * a.rs_sym];
+              const float2 rp = rot_pos[s];
+              const int64_t pb = k * a.ps_re + (hp.pil_sym0 + s) * a.ps_sym;
+              float2 est = cmul(pil[pb + (2 * c) * a.ps_l], cmul(h0, rp));
+              if (2 * c + 1 < L) est = cadd(est, cmul(pil[pb + (2 * c + 1) * a.ps_l], cmul(h1, rp)));
+              const float dr = x.x - beta_f * est.x, di = x.y - beta_f * est.y;
+              noise_part += dr * dr + di * di;
+            }
+          }
+        }
+      }
+      double v[3] = {(double)epre_part, (double)noise_part, (double)rsrp_part};
+      block_sum<3>(v, red);
+      tot_epre += v[0];
+      tot_noise += v[1];
+      tot_rsrp += plan->beta * plan->beta * v[2] * (double)n_dmrs;
+    }
+
+    STAMP(6);
+    // ------------------------------------------------------------ time alignment (S8)
+    // x[n] = P[k] at the pilot subcarriers of the LAST CDM group (for every layer, T:672-675), else 0;
+    // X[k] = sum_n x[n] W^(nk), W = exp(+j 2 pi / 4096), wanted only for k in [0,144) U [3952,4096).
+    // n = r + 16 n':  X[k] = sum_r W^(rk) Y_r[k mod 256],  Y_r = 256-point IDFT of x[r + 16 n'] done as
+    // two radix-16 passes in LDS; residues r without pilots (half of them for a comb-2 DM-RS) are skipped.
+    if (!(CE_ABLATE & 1)) {
+      float pw0 = 0.f, pw1 = 0.f;  // bins tid and tid + NT of the 288 examined (b < 144: delay side, else advance side)
+      const int b0 = tid, b1 = tid + NT;
+      constexpr int NB = 2 * CE_TA_HALF;
+      const int nres = hp.ta_nres;
+      const uint16_t* inv = ta_inv + hp.ta_inv_off;
+      const int ri = tid >> 4, a4 = tid & 15;
+      const unsigned long long res_packed = hp.ta_res_packed;
+      auto bin_power = [&](int k) -> float {
+        const int q = k & 255, off = (q & 15) * 17 + (q >> 4);
+        float2 acc = make_float2(0.f, 0.f);
+        for (int i = 0; i < nres; ++i) {
+          const int m = ((int)((res_packed >> (4 * i)) & 15u) * k) & (CE_FFT_SIZE - 1);  // W4096^(r k)
+          acc = cadd(acc, cmul(cmul(tw256[m >> 4], tw16[m & 15]), scratch[i * CE_TA_ROW + off]));
+        }
+        return acc.x * acc.x + acc.y * acc.y;
+      };
+      // subcarrier n -> ordinal of the pilot it carries (last CDM group), or -1
+      const int contig = hp.contig, dpp_last = hp.dpp[NC - 1], prb0 = hp.prb_start, nprb = hp.n_prbs;
+      const unsigned long long ord_packed = hp.ord_packed;
+      auto pilot_at = [&](int n) -> int {
+        if (contig) {
+          const int q = n / 12, rem = n - 12 * q, pq = q - prb0;
+          const int o = (int)((ord_packed >> (4 * rem)) & 15u);
+          return (pq >= 0 && pq < nprb && o != 15) ? pq * dpp_last + o : -1;
+        }
+        const unsigned idx = inv[n];
+        return idx == 0xFFFFu ? -1 : (int)idx;
+      };
+#pragma unroll 1
+      for (int l = 0; l < L; ++l) {
+        const float2* Pl = Ph + l * n_re_pad;
+        if (ri < nres) {  // pass 1: DFT16 over b of x[r + 16 a + 256 b], times W256^(a c)
+          const int r = (int)((res_packed >> (4 * ri)) & 15u);
+          float2 v[16];
+#pragma unroll
+          for (int b = 0; b < 16; ++b) {
+            const int idx = pilot_at(r + 16 * a4 + 256 * b);
+            v[b] = idx >= 0 ? Pl[idx] : make_float2(0.f, 0.f);
+          }
+          idft16(v);
+          float2* dst = scratch + ri * CE_TA_ROW + a4;
+          dst[0] = v[0];
+#pragma unroll
+          for (int c = 1; c < 16; ++c) dst[c * 17] = cmul(v[c], tw256[a4 * c]);
+        }
+        __syncthreads();
+        if (ri < nres) {  // pass 2 (in place): DFT16 over a for fixed c = a4 -> Y_r[c + 16 d] at [c*17 + d]
+          float2* rowp = scratch + ri * CE_TA_ROW + a4 * 17;
+          float2 v[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = rowp[i];
+          idft16(v);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) rowp[i] = v[i];
+        }
+        __syncthreads();
+        if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0);
+        if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1);
         __syncthreads();
       }
       // arg-max with first-index tie break on each side: key = (power bits, ~index)
       unsigned long long kh = 0ull, kt = 0ull;
-      {
-        const unsigned long long key0 = ((unsigned long long)__float_as_uint(pw0) << 32);
-        if (tid < CE_TA_HALF) kh = key0 | (unsigned)(0xFFFFFFFFu - (unsigned)tid);
-        else kt = key0 | (unsigned)(0xFFFFFFFFu - (unsigned)(tid - CE_TA_HALF));
-        if (tid + NT < 2 * CE_TA_HALF) {
-          const unsigned long long key1 = ((unsigned long long)__float_as_uint(pw1) << 32) |
-                                          (unsigned)(0xFFFFFFFFu - (unsigned)(tid + NT - CE_TA_HALF));
-          kt = key1 > kt ? key1 : kt;
+      auto offer = [&](int b, float pw) {
+        if (b < NB) {
+          const int idx = b < CE_TA_HALF ? b : b - CE_TA_HALF;
+          const unsigned long long key = ((unsigned long long)__float_as_uint(pw) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
+          if (b < CE_TA_HALF) kh = key > kh ? key : kh;
+          else kt = key > kt ? key : kt;
         }
-      }
+      };
+      offer(b0, pw0);
+      offer(b1, pw1);
       kh = wave_max_u64(kh);
       kt = wave_max_u64(kt);
       unsigned long long* ared = reinterpret_cast<unsigned long long*>(red);
@@ -442,137 +817,272 @@ __global__ __launch_bounds__(NT) void ce_estimate_kernel(const CeDevPlan* __rest
       }
       __syncthreads();
     }
+  }
 
-    // ------------------------------------------------------------ residual noise, RSRP (S9, S11)
-    {
-      float noise_part = 0.f, rsrp_part = 0.f;
-      for (int k = tid; k < n_re; k += NT) {
+  STAMP(7);
+  // ---------------------------------------------------------------- slot-level epilogue (T:898-937)
+  const bool apply_rot = cfo_comp && plan->cfo_estimated && !(CE_ABLATE & 16);
+  if (tid < 16) {
+    double cfo = 0.0;  // running mean over the hops that estimated one (T:605-609)
+    bool have = false;
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-          const float2 v = Ph[l * n_re_pad + k];
-          rsrp_part += v.x * v.x + v.y * v.y;
-        }
-#pragma unroll
-        for (int c = 0; c < (L + 1) / 2; ++c) {
-          const int64_t sc = re_idx[hp.re_off[c] + k];
-          const float2 h0 = Ph[(2 * c) * n_re_pad + k];
-          const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * n_re_pad + k] : make_float2(0.f, 0.f);
-          for (int s = 0; s < n_dmrs; ++s) {
-            const float2 x = rx[sc * a.rs_sc + hp.dmrs_sym[s] * a.rs_sym];
-            const float2 rp = rot_pos[h * 16 + s];
-            const int64_t pb = k * a.ps_re + (hp.pil_sym0 + s) * a.ps_sym;
-            float2 est = cmul(pil[pb + (2 * c) * a.ps_l], cmul(h0, rp));
-            if (2 * c + 1 < L) est = cadd(est, cmul(pil[pb + (2 * c + 1) * a.ps_l], cmul(h1, rp)));
-            const float dr = x.x - beta_f * est.x, di = x.y - beta_f * est.y;
-            noise_part += dr * dr + di * di;
-          }
-        }
+    for (int h = 0; h < NH; ++h)
+      if (plan->hop[h].has_cfo && !(CE_ABLATE & 16)) {
+        cfo = have ? (cfo + misc[h]) / 2 : misc[h];
+        have = true;
       }
-      double v[3] = {(double)epre_part, (double)noise_part, (double)rsrp_part};
-      block_sum<3>(v, red);
-      tot_epre += v[0];
-      tot_noise += v[1];
-      tot_rsrp += plan->beta * plan->beta * v[2] * (double)n_dmrs;
+    float2 r = make_float2(1.f, 0.f);
+    if (apply_rot && tid < CE_MAX_SYMBOLS) {
+      float sn, cs;
+      sincospi_f64arg(2.0 * sst_l[tid] * cfo, &sn, &cs);
+      r = make_float2(cs, sn);
+    }
+    rot_final[tid] = r;
+    if (tid == 0) {
+      const double np = plan->n_pilots;
+      a.rsrp[item] = tot_rsrp / np / (double)L;
+      a.epre[item] = tot_epre / np;
+      a.noise[item] = tot_noise / plan->noise_den;
+      a.ta[item] = (NH == 2) ? tot_ta / 2.0 : tot_ta;
+      a.cfo[item] = plan->cfo_estimated ? cfo * plan->scs : __longlong_as_double(0x7FF8000000000000ll);
     }
   }
+  __syncthreads();
 
-  // ---------------------------------------------------------------- scalars (T:898-937)
-  if (tid == 0) {
-    const double np = plan->n_pilots;
-    a.rsrp[item] = tot_rsrp / np / (double)L;
-    a.epre[item] = tot_epre / np;
-    a.noise[item] = tot_noise / plan->noise_den;
-    a.ta[item] = (NH == 2) ? tot_ta / 2.0 : tot_ta;
-    a.cfo[item] = plan->cfo_estimated ? misc[2] * plan->scs : __longlong_as_double(0x7FF8000000000000ll);
-  }
-
+  STAMP(8);
+#if CE_PERSIST
+  if (wg + gridDim.x < a.n_items) load_hop(item_of(wg + gridDim.x, a.n_ports, a.n_items), 0);  // prefetch for the next trip
+#endif
   // ---------------------------------------------------------------- interpolate + replicate + CFO ramp (S10)
   const int n_sym = plan->n_sym;
   const int row = n_sym * L;  // complex values per subcarrier
   const int64_t total = (int64_t)plan->n_sc * row;
   float2* out = a.out + item * total;
 
-  auto elem = [&](int sc, int rem) -> float2 {
-    const int sym = rem / L, l = rem - sym * L;
-    float2 val = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int h = NH - 1; h >= 0; --h) {  // a later hop overwrites an earlier one (T:872-896)
-      const CeDevHop& hp = plan->hop[h];
-      const int p = sc - hp.sc0;
-      if (sym >= hp.sym0 && sym < hp.sym1 && p >= 0 && p < hp.n_sc_hop) {
-        const int c = l >> 1;
-        const int q = p / 12, r = p - 12 * q;
-        const float2 t = tab[(h * CE_MAX_CDM + c) * 12 + r];
-        int ro = q * hp.dpp[c] + __float_as_int(t.y);
-        int lo = ro - 1;
-        if (p >= hp.last_idx[c]) lo = ro = n_re - 1;
-        lo = lo < 0 ? 0 : lo;
-        const float2* Pl = P + (h * L + l) * n_re_pad;
-        const float2 u = Pl[lo], v = Pl[ro];
-        val = make_float2(u.x + t.x * (v.x - u.x), u.y + t.x * (v.y - u.y));
-        if (apply_rot) val = cmul(val, rot_final[sym]);
-        break;
-      }
-    }
-    return val;
+  // linear interpolation at hop-relative subcarrier p of layer l (T:311-338); exact pilot value outside
+  // the first/last pilot, left + alpha*(right-left) elsewhere (also AT pilots, as the reference does)
+  auto interp_at = [&](int h, int l, int p) -> float2 {
+    const CeDevHop& hp = plan->hop[h];
+    const int c = l >> 1;
+    const int q = p / 12, r = p - 12 * q;
+    const float2 t = tab[(h * CE_MAX_CDM + c) * 12 + r];
+    int ro = q * hp.dpp[c] + __float_as_int(t.y);
+    int lo = ro - 1;
+    if (p >= hp.last_idx[c]) lo = ro = n_re - 1;
+    lo = lo < 0 ? 0 : lo;
+    const float2* Pl = P + (h * L + l) * n_re_pad;
+    const float2 u = Pl[lo], v = Pl[ro];
+    return make_float2(u.x + t.x * (v.x - u.x), u.y + t.x * (v.y - u.y));
   };
 
-  if ((row & 1) == 0) {
+  if (CE_ABLATE & 8) {
+  } else if (n_sym == CE_MAX_SYMBOLS) {
+    // Fast writer.  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
+    // each of ACTIVE (a multiple of 252) threads owns ONE (symbol, layer) float4 phase for the whole item:
+    // its two rotation phasors and hop/layer selection live in registers, and a workgroup iteration
+    // stores ACTIVE*16 contiguous bytes.  The interpolated, un-rotated response H[hop][layer][sc] is staged in the LDS
+    // scratch, a chunk of subcarriers at a time.
+    constexpr int ROW4 = 7 * L;             // float4 per subcarrier
+    constexpr int ACTIVE = (NT / 252) * 252;
+    constexpr int SC_STEP = ACTIVE / ROW4;  // subcarriers per workgroup iteration
+    const int ch_log2 = plan->wr_ch_log2, CH = 1 << ch_log2;
+    const int ph = tid % ROW4, sc_lane = tid / ROW4;
+    int hsel[2], lsel[2];
+    float2 rsel[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int rem = 2 * ph + e, sym = rem / L;
+      lsel[e] = rem - sym * L;
+      int h = -1;
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh)
+        if (sym >= plan->hop[hh].sym0 && sym < plan->hop[hh].sym1) h = hh;  // a later hop overwrites (T:872-896)
+      hsel[e] = h < 0 ? 0 : h;
+      rsel[e] = h < 0 ? make_float2(0.f, 0.f) : rot_final[sym];  // rot_final == 1 when no CFO ramp applies
+    }
     float4* out4 = reinterpret_cast<float4*>(out);
-    const int64_t npairs = total >> 1;
-    int sc = (2 * tid) / row, rem = (2 * tid) - sc * row;
-    const int dsc = (2 * NT) / row, drem = (2 * NT) - dsc * row;
-    for (int64_t f = tid; f < npairs; f += NT) {
-      const float2 v0 = elem(sc, rem), v1 = elem(sc, rem + 1);
-      out4[f] = make_float4(v0.x, v0.y, v1.x, v1.y);
-      rem += drem;
-      sc += dsc;
-      if (rem >= row) {
-        rem -= row;
-        ++sc;
+    if constexpr (SC_STEP % 12 == 0) {
+      // Direct form (L = 1, 3): a thread's subcarriers advance by whole PRBs, so its RE position inside the
+      // PRB -- hence its interpolation weight and anchor ordinals (T:325-337) -- is constant: interpolate
+      // straight from P in LDS, no staging buffer, no barrier.
+      constexpr int QS = SC_STEP / 12;
+      const int r12 = sc_lane % 12;
+      const float2* Pe[2];
+      float al[2];
+      int ro[2], q[2], nprb[2], dro[2];
+      bool tail_r[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const CeDevHop& hp = plan->hop[hsel[e]];
+        const int c = lsel[e] >> 1;
+        const float2 t = tab[(hsel[e] * CE_MAX_CDM + c) * 12 + r12];
+        al[e] = t.x;
+        Pe[e] = P + (hsel[e] * L + lsel[e]) * n_re_pad;
+        q[e] = sc_lane / 12 - hp.prb_start;
+        nprb[e] = hp.n_prbs;
+        dro[e] = QS * hp.dpp[c];
+        ro[e] = q[e] * hp.dpp[c] + __float_as_int(t.y);
+        tail_r[e] = 12 * (hp.n_prbs - 1) + r12 >= hp.last_idx[c];
+      }
+      if (tid < ACTIVE) {
+        float4* o = out4 + tid;
+        const int n_iter = (plan->n_sc - sc_lane + SC_STEP - 1) / SC_STEP;
+#pragma unroll 2
+        for (int it = 0; it < n_iter; ++it) {
+          float2 y[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (e == 1 && L == 1 && NH == 1) {  // same subcarrier, same layer, same hop: reuse the interpolation
+              y[1] = y[0];
+            } else {
+              const bool valid = (unsigned)q[e] < (unsigned)nprb[e];
+              int hi = ro[e], lo = ro[e] - 1;
+              if (q[e] == nprb[e] - 1 && tail_r[e]) lo = hi = n_re - 1;  // at/after the last pilot: hold (T:316,321)
+              lo = lo < 0 ? 0 : lo;                                       // at/before the first pilot: hold (T:315,320)
+              if (!valid) lo = hi = 0;
+              const float2 u = Pe[e][lo], v = Pe[e][hi];
+              y[e] = valid ? make_float2(u.x + al[e] * (v.x - u.x), u.y + al[e] * (v.y - u.y)) : make_float2(0.f, 0.f);
+              q[e] += QS;
+              ro[e] += dro[e];
+            }
+          }
+          const float2 ya = cmul(y[0], rsel[0]), yb = cmul(y[1], rsel[1]);
+          store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
+          o += ACTIVE;
+        }
+      }
+    } else {
+      const float2* HA = scratch + ((hsel[0] * L + lsel[0]) << ch_log2);
+      const float2* HB = scratch + ((hsel[1] * L + lsel[1]) << ch_log2);
+#pragma unroll 1
+      for (int c0 = 0; c0 < plan->n_sc; c0 += CH) {
+        const int cn = min(CH, plan->n_sc - c0);
+        for (int i = tid; i < NH * L * CH; i += NT) {
+          const int s = i & (CH - 1), hl = i >> ch_log2;
+          if (s < cn) {
+            const int h = hl / L, l = hl - h * L;
+            const int p = c0 + s - plan->hop[h].sc0;
+            float2 v = make_float2(0.f, 0.f);
+            if (p >= 0 && p < plan->hop[h].n_sc_hop) v = interp_at(h, l, p);
+            scratch[i] = v;
+          }
+        }
+        __syncthreads();
+        if (c0 == 0) STAMP(9);
+        if (tid < ACTIVE) {
+          float4* o = out4 + (int64_t)c0 * ROW4 + tid;
+#pragma unroll 4
+          for (int s = sc_lane; s < cn; s += SC_STEP) {
+            const float2 va = HA[s], vb = HB[s];
+            const float2 ya = cmul(va, rsel[0]), yb = cmul(vb, rsel[1]);
+            store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
+            o += ACTIVE;
+          }
+        }
+        __syncthreads();
       }
     }
   } else {
-    for (int64_t e = tid; e < total; e += NT) {
-      const int sc = (int)(e / row);
-      out[e] = elem(sc, (int)(e - (int64_t)sc * row));
+    // generic writer (any n_sym): decode (subcarrier, symbol, layer) per element
+    auto elem = [&](int sc, int rem) -> float2 {
+      const int sym = rem / L, l = rem - sym * L;
+      float2 val = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int h = NH - 1; h >= 0; --h) {
+        const CeDevHop& hp = plan->hop[h];
+        const int p = sc - hp.sc0;
+        if (sym >= hp.sym0 && sym < hp.sym1 && p >= 0 && p < hp.n_sc_hop) {
+          val = interp_at(h, l, p);
+          if (apply_rot) val = cmul(val, rot_final[sym]);
+          break;
+        }
+      }
+      return val;
+    };
+    if ((row & 1) == 0) {
+      float4* out4 = reinterpret_cast<float4*>(out);
+      const int64_t npairs = total >> 1;
+      int sc = (2 * tid) / row, rem = (2 * tid) - sc * row;
+      const int dsc = (2 * NT) / row, drem = (2 * NT) - dsc * row;
+      for (int64_t f = tid; f < npairs; f += NT) {
+        const float2 v0 = elem(sc, rem), v1 = elem(sc, rem + 1);
+        out4[f] = make_float4(v0.x, v0.y, v1.x, v1.y);
+        rem += drem;
+        sc += dsc;
+        if (rem >= row) {
+          rem -= row;
+          ++sc;
+        }
+      }
+    } else {
+      for (int64_t e = tid; e < total; e += NT) {
+        const int sc = (int)(e / row);
+        out[e] = elem(sc, (int)(e - (int64_t)sc * row));
+      }
     }
   }
+  STAMP(10);
+  __syncthreads();  // the next item reuses P, the scratch and the phasor tables
+  }  // item loop
 }
 
-template <int L, int NH>
-int launch_t(const CeDevPlan* dplan, const uint16_t* re_idx, const float2* tw, const CeKernelArgs& args, int lds,
-             hipStream_t stream) {
-  hipLaunchKernelGGL((ce_estimate_kernel<L, NH>), dim3((unsigned)args.n_items), dim3(NT), lds, stream, dplan, re_idx,
-                     tw, args);
+#if defined(CE_STAMPS)
+}  // namespace
+extern "C" int ce_debug_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ce_stamps), &p, sizeof(p)); }
+namespace {
+#endif
+
+template <int L, int NH, int ND>
+int launch_t(const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv, const float2* tw,
+             const CeKernelArgs& args, int lds, int grid_cap, hipStream_t stream) {
+  const unsigned grid = (unsigned)((!CE_PERSIST || args.n_items < grid_cap) ? args.n_items : grid_cap);
+  hipLaunchKernelGGL((ce_estimate_kernel<L, NH, ND>), dim3(grid), dim3(NT), lds, stream, dplan, re_idx, ta_inv, tw,
+                     args);
   return (int)hipGetLastError();
 }
 
-template <int L, int NH>
-int prepare_t(int lds) {
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_estimate_kernel<L, NH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+// sets the dynamic-LDS limit and reports how many workgroups fit a CU (the persistent grid is CUs x that)
+template <int L, int NH, int ND>
+int prepare_t(int lds, int* blocks_per_cu) {
+  const void* fn = reinterpret_cast<const void*>(&ce_estimate_kernel<L, NH, ND>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return (int)e;
+  int nb = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NT, lds);
+  *blocks_per_cu = nb > 0 ? nb : 1;
+  return (int)e;
 }
 
 }  // namespace
 
-#define CE_DISPATCH(FN, ...)                                      \
-  switch (n_layers * 10 + n_hops) {                               \
-    case 11: return FN<1, 1>(__VA_ARGS__);                        \
-    case 12: return FN<1, 2>(__VA_ARGS__);                        \
-    case 21: return FN<2, 1>(__VA_ARGS__);                        \
-    case 22: return FN<2, 2>(__VA_ARGS__);                        \
-    case 31: return FN<3, 1>(__VA_ARGS__);                        \
-    case 32: return FN<3, 2>(__VA_ARGS__);                        \
-    case 41: return FN<4, 1>(__VA_ARGS__);                        \
-    case 42: return FN<4, 2>(__VA_ARGS__);                        \
-    default: return -1;                                           \
+// (layers, hops, register-path DM-RS count): ND in {1,2} only exists for one CDM group (L <= 2)
+#define CE_DISPATCH(FN, ...)                                       \
+  switch (n_layers * 100 + n_hops * 10 + reg_nd) {                 \
+    case 110: return FN<1, 1, 0>(__VA_ARGS__);                     \
+    case 111: return FN<1, 1, 1>(__VA_ARGS__);                     \
+    case 112: return FN<1, 1, 2>(__VA_ARGS__);                     \
+    case 120: return FN<1, 2, 0>(__VA_ARGS__);                     \
+    case 121: return FN<1, 2, 1>(__VA_ARGS__);                     \
+    case 122: return FN<1, 2, 2>(__VA_ARGS__);                     \
+    case 210: return FN<2, 1, 0>(__VA_ARGS__);                     \
+    case 211: return FN<2, 1, 1>(__VA_ARGS__);                     \
+    case 212: return FN<2, 1, 2>(__VA_ARGS__);                     \
+    case 220: return FN<2, 2, 0>(__VA_ARGS__);                     \
+    case 221: return FN<2, 2, 1>(__VA_ARGS__);                     \
+    case 222: return FN<2, 2, 2>(__VA_ARGS__);                     \
+    case 310: return FN<3, 1, 0>(__VA_ARGS__);                     \
+    case 320: return FN<3, 2, 0>(__VA_ARGS__);                     \
+    case 410: return FN<4, 1, 0>(__VA_ARGS__);                     \
+    case 420: return FN<4, 2, 0>(__VA_ARGS__);                     \
+    default: return -1;                                            \
   }
 
-int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const float2* tw,
-              const CeKernelArgs& args, int lds_bytes, hipStream_t stream) {
-  const int n_layers = hplan.n_layers, n_hops = hplan.n_hops;
-  CE_DISPATCH(launch_t, dplan, re_idx, tw, args, lds_bytes, stream)
+int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,
+              const float2* tw, const CeKernelArgs& args, int lds_bytes, int grid_cap, hipStream_t stream) {
+  const int n_layers = hplan.n_layers, n_hops = hplan.n_hops, reg_nd = hplan.reg_nd;
+  CE_DISPATCH(launch_t, dplan, re_idx, ta_inv, tw, args, lds_bytes, grid_cap, stream)
 }
 
-int ce_prepare_kernel(int n_layers, int n_hops, int lds_bytes) { CE_DISPATCH(prepare_t, lds_bytes) }
+int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int lds_bytes, int* blocks_per_cu) {
+  CE_DISPATCH(prepare_t, lds_bytes, blocks_per_cu)
+}

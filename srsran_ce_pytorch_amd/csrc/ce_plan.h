@@ -8,7 +8,13 @@
 
 #define CE_MAX_RC_TAPS 31   // stride 1, 3 RB (T:184-234)
 #define CE_TA_HALF 144      // floor(72 * 4096 / 2048) bins each side (T:682)
-#define CE_THREADS 256
+#ifndef CE_THREADS
+#define CE_THREADS 256      // workgroup size (4 waves); 512 also builds
+#endif
+#define CE_KPT (CE_THREADS == 256 ? 7 : 4)  // pilot REs per thread on the register path (n_re <= CE_KPT * CE_THREADS)
+#define CE_CONV_C 9         // consecutive RC-FIR outputs per thread (sliding window), conv threads = CE_THREADS - 64
+#define CE_RCZ_LEN (CE_MAX_RC_TAPS + 2 * (CE_CONV_C - 1))
+#define CE_TA_ROW 272       // 16 x 17 complex per residue block (padded against LDS bank conflicts)
 
 struct CeDevHop {
   int32_t n_dmrs;                     // DM-RS symbols in the hop
@@ -23,16 +29,30 @@ struct CeDevHop {
   int32_t r_ord[CE_MAX_CDM][12];      // right-anchor ordinal inside the PRB for RE r (T:325)
   float alpha[CE_MAX_CDM][12];        // (pos-left)/(right-left) in float32 (T:333-337)
   double two_pi_nsamples;             // 2*pi*nSamples (T:418-426)
+  int32_t ta_nres;                    // residues mod 16 of the subcarriers the TA scatter touches (T:672-675)
+  int32_t ta_res[16];
+  int32_t ta_inv_off;                 // offset of this hop's subcarrier -> pilot-ordinal table (0xFFFF = no pilot)
+  int32_t contig;                     // maskPRBs == [PRBstart, PRBstart+nPRBs): pilot positions are computed, not looked up
+  int32_t prb_start, n_prbs;
+  uint32_t div_magic[CE_MAX_CDM];     // floor(2^32 / dpp) + 1: k / dpp == umulhi(k, magic) for k < 2^16
+  uint64_t pos_packed[CE_MAX_CDM];    // 4 bits per pilot j of a PRB: its RE position
+  uint64_t ord_packed;                // last CDM group: 4 bits per RE r: pilot ordinal inside the PRB, 15 = not a pilot
+  uint64_t ta_res_packed;             // 4 bits per entry of ta_res
 };
 
 struct CeDevPlan {
   int32_t n_sc, n_sym, n_layers, n_cdm, n_hops, smoothing, cfo_comp, interp;
   int32_t n_re, n_re_pad, n_pils, rc_len, ext_len, filt_lpp;
-  int32_t cfo_estimated, apply_final_rot_possible;
+  int32_t cfo_estimated, reg_nd;      // reg_nd: DM-RS symbols per hop held in registers (0 = re-read path)
+  int32_t scratch_bytes, wr_ch_log2;  // LDS scratch size; log2 of the writer's subcarrier chunk
   float beta_f;
   double beta, scs, denom_cdm, n_pilots, noise_den;
   double sst[CE_MAX_SYMBOLS];         // symbolStartTime (T:809-820)
+  double sst_dmrs[CE_MAX_HOPS][CE_MAX_SYMBOLS];  // symbolStartTime at each hop's DM-RS symbols
   double rc[CE_MAX_RC_TAPS];          // RC taps, unit sum (T:184-234)
+  double rcz[CE_RCZ_LEN];             // the same taps with CE_CONV_C-1 zeros on both sides (windowed FIR)
+  double vp_mx, vp_inv_n, vp_inv_denom;  // regression constants of the n_pils-point straight-line fit (T:105-117)
+  int32_t filt_windowed, pad1;        // 1: n_re <= (CE_THREADS-64)*CE_CONV_C -> sliding-window FIR
   CeDevHop hop[CE_MAX_HOPS];
 };
 
@@ -49,22 +69,24 @@ struct CeKernelArgs {
 
 // LDS carve-up shared by host (sizing) and device (offsets); all offsets multiples of 16 B.
 struct CeLdsLayout {
-  int32_t off_p, off_scratch, off_red, off_rot, off_tab, off_misc, total;
+  int32_t off_p, off_scratch, off_red, off_rot, off_tab, off_misc, off_tw, off_rcz, total;
 };
 
-static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_layers, int n_re_pad) {
+static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_layers, int n_re_pad, int scratch_bytes) {
   CeLdsLayout l;
   int o = 0;
   l.off_p = o;        o += n_hops * n_layers * n_re_pad * 8;
-  l.off_scratch = o;  o += CE_FFT_SIZE * 8;
+  l.off_scratch = o;  o += (scratch_bytes + 15) & ~15;
   l.off_red = o;      o += (CE_THREADS / 64) * 16 * 8;           // 16 doubles per wave
   l.off_rot = o;      o += (1 + 2 * CE_MAX_HOPS) * 16 * 8;       // final, per-hop -/+ phasors, 16 float2 each
   l.off_tab = o;      o += CE_MAX_HOPS * CE_MAX_CDM * 12 * 8;    // {alpha, r_ord} pairs
-  l.off_misc = o;     o += 16 * 8;                               // doubles: cfo_hop[2], cfo_final, ...
+  l.off_misc = o;     o += 48 * 8;                               // doubles: cfo_hop[2], pad[2], sst[16], sst_dmrs[2][14]
+  l.off_tw = o;       o += (256 + 16) * 8;                       // W256^j, W4096^i for the TA transform
+  l.off_rcz = o;      o += ((CE_RCZ_LEN + 1) & ~1) * 8;          // zero-padded RC taps (float64)
   l.total = (o + 15) & ~15;
   return l;
 }
 
-int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const float2* tw,
-              const CeKernelArgs& args, int lds_bytes, hipStream_t stream);
-int ce_prepare_kernel(int n_layers, int n_hops, int lds_bytes);
+int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,
+              const float2* tw, const CeKernelArgs& args, int lds_bytes, int grid_cap, hipStream_t stream);
+int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int lds_bytes, int* blocks_per_cu);
