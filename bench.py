@@ -106,6 +106,7 @@ def main():
     import torch
     import torch.distributed as dist
     from srsran_ce_pytorch_amd import estimator as E
+    from srsran_ce_pytorch_amd.sharding import aggregate_slots_per_second, max_over_ranks
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -136,10 +137,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # measurement only, not data path
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+    elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms], dev)  # measurement only, not data path
 
     # sanity: the batch really was estimated (finite outputs, CFO in the generated range)
     assert bool(torch.isfinite(out[1]).all()) and bool(torch.isfinite(out[0][-1, -1].real).all())
@@ -147,7 +145,15 @@ def main():
     bytes_per_slot = n_ports * plan.alg_bytes_per_item + plan.pilot_bytes_per_slot
     bytes_per_launch = n_slots * bytes_per_slot
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    value = world * n_slots * args.steps / elapsed
+    value = aggregate_slots_per_second(n_slots, args.steps, elapsed, world)
+    # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the
+    # MI355X guide prescribes for gfx950); collected once per round and committed under profiles/
+    traffic, traffic_src = None, None
+    prof = ROOT / "profiles" / "round1_summary.json"
+    if prof.exists():
+        pj = json.loads(prof.read_text())
+        if pj.get("workload", "").startswith(args.workload) and n_slots == wl["slots"]:
+            traffic, traffic_src = pj["hbm_traffic_bytes_per_launch"], "profiles/round1_summary.json"
     line = {
         "metric": "slots/sec (273-PRB PUSCH, 4 Rx)" if n_ports == 4 else f"slots/sec (273-PRB PUSCH, {n_ports} Rx)",
         "value": value, "unit": "slots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,8 +163,8 @@ def main():
                    "layers": 1, "rx_ports": n_ports, "smoothing": wl["smoothing"], "slots_per_gpu": n_slots,
                    "global_slots": world * n_slots, "rx_layout": "[slot][port][sym][sc]", "parallelism": f"slot-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "ce_estimate_kernel<1,1>", "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "ce_estimate_kernel<1,1,2>", "kernel_ms": kernel_ms,
                      "alg_bytes_per_slot": bytes_per_slot, "alg_bytes_per_launch": bytes_per_launch},
     }
     if cpu is not None:

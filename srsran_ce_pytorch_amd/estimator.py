@@ -209,6 +209,8 @@ def estimate_with_plan(plan: Plan, received_rg: torch.Tensor, pilots: torch.Tens
     for t in out[1:]:
         if not t.is_contiguous() or t.dtype != torch.float64 or t.numel() != B * R:
             raise ValueError("scalar outputs must be contiguous float64 [B,R] tensors")
+    if B * R == 0:
+        return out                                           # empty batch: nothing to launch
     stream = torch.cuda.current_stream(dev).cuda_stream
     rc = lib.ce_estimate_batch(plan._handle, received_rg.data_ptr(), _strides4(received_rg), pilots4.data_ptr(),
                                _strides4(pilots4), B, R, ch.data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
