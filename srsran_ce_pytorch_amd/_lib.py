@@ -14,7 +14,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
-LIB_PATH = CSRC / "libce_hip.so"
+LIB_PATH = Path(os.environ.get("CE_HIP_LIB", CSRC / "libce_hip.so"))   # override: diagnostic builds (tools/)
 SOURCES = ["ce_api.hip", "ce_kernels.hip"]
 
 CE_ABI_VERSION = 1

@@ -253,7 +253,9 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
       P.vp_inv_n = 1.0 / n;
       P.vp_inv_denom = P.n_pils > 1 ? 1.0 / (sxx - n * P.vp_mx * P.vp_mx) : 0.0;
     }
-    P.filt_windowed = (n_re <= (CE_THREADS - 64) * CE_CONV_C && P.n_pils <= 12 && P.n_pils <= rc.size() / 2 + CE_CONV_C) ? 1 : 0;
+    // windowed FIR: band fits 9 outputs x 192 threads, both edge zones (len(rc)/2 outputs each) are disjoint
+    P.filt_windowed = (n_re <= (CE_THREADS - 64) * CE_CONV_C && P.n_pils <= 12 && n_re >= 2 * ((int)rc.size() / 2) &&
+                       (int)rc.size() == 15) ? 1 : 0;
   }
 
   // LDS scratch: TA residue blocks | virtual-pilot-extended band for the RC FIR | writer's H chunk

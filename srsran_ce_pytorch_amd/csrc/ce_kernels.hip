@@ -30,7 +30,7 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #define CE_ABLATE 0   // timing experiments only (tools/ablate.py): 1 TA, 2 smoothing, 4 residual, 8 writer, 16 CFO, 32 input loads
 #endif
 #ifndef CE_MIN_WAVES
-#define CE_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
+#define CE_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for (3 workgroups per CU; 4 would spill)
 #endif
 #ifndef CE_PERSIST
 #define CE_PERSIST 0      // 1: persistent workgroups that prefetch the next item's pilots before writing
@@ -48,10 +48,15 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 __device__ unsigned long long* g_ce_stamps;
 #define STAMP(i)                                                      \
   do {                                                                \
-    if (threadIdx.x == 0) g_ce_stamps[item * 16 + (i)] = wall_clock64(); \
+    if (threadIdx.x == 0 && g_ce_stamps) g_ce_stamps[item * 16 + (i)] = wall_clock64(); \
+  } while (0)
+#define STAMP_W3(i)                                                   \
+  do {                                                                \
+    if (threadIdx.x == NT - 64 && g_ce_stamps) g_ce_stamps[item * 16 + (i)] = wall_clock64(); \
   } while (0)
 #else
 #define STAMP(i)
+#define STAMP_W3(i)
 #endif
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -273,6 +278,91 @@ __device__ __forceinline__ int pilot_sc(const CeDevHop& hp, const uint16_t* __re
   return re_idx[hp.re_off[c] + k];
 }
 
+// RC FIR over one layer's pilots, in place: conv([virtual head ; P ; virtual tail], rc, "same") cropped back
+// to P (T:649-664), float64 MACs (T:477-490).  PAD = len(rc) / 2 (the 31-tap instantiation also serves shorter
+// odd lengths through zero taps).  Waves 0..2: each thread owns CE_CONV_C consecutive outputs and slides a
+// fully unrolled window over P (one LDS read per input sample, taps held in registers).  Last wave: fits the
+// virtual pilots (two 16-lane groups), then its first 2*PAD lanes compute the outputs whose window reaches
+// past a band edge.  One barrier separates all reads of P from the writes.
+template <int PAD>
+__device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils, int pad_rt, const double* rcz,
+                                                float2* vpb, int tid, double vmx, double vin, double vid) {
+  constexpr int CV = CE_CONV_C, NCV = NT - 64, NTAP = 2 * PAD + 1;
+  // rc_ext[j], j = 0..NTAP-1: the actual taps centred in the PAD-wide template (zeros outside)
+  const double* rc = rcz + (CV - 1) - (PAD - pad_rt);
+  const int m0 = tid * CV;
+  double ar[CV], ai[CV];      // defined on the FIR threads only (not live across the virtual-pilot branch)
+  double er = 0.0, ei = 0.0;  // edge output of this lane (last wave)
+  int em = -1;
+  if (tid >= NCV) {
+    const int q = tid - NCV;
+    if (q < 32) {
+      const int e = q >> 4;
+      virtual_pilots(Pl, n_re, n_pils, e != 0, q & 15, vmx, vin, vid, [&](int dist, float2 val) { vpb[e * 16 + dist] = val; });
+    }
+    if (q < 2 * PAD) {  // same wave as the lanes that just wrote vpb: DS operations of a wave execute in order
+      em = q < PAD ? q : n_re - 2 * PAD + q;
+#pragma unroll
+      for (int j = 0; j < NTAP; ++j) {
+        const int idx = em + PAD - j;
+        float2 x = make_float2(0.f, 0.f);
+        if (idx < 0) {
+          if (-1 - idx < n_pils) x = vpb[-1 - idx];
+        } else if (idx >= n_re) {
+          if (idx - n_re < n_pils) x = vpb[16 + idx - n_re];
+        } else {
+          x = Pl[idx];
+        }
+        const double h = rc[j];
+        er += h * (double)x.x;
+        ei += h * (double)x.y;
+      }
+    }
+  } else {
+    // y[m0+o] = sum_j rc[j] x[m0 + o + PAD - j]; input sample w (index m0 - PAD + w) meets tap j = o + 2 PAD - w
+#pragma unroll
+    for (int o = 0; o < CV; ++o) ar[o] = ai[o] = 0.0;
+    double h[PAD + 1];
+#pragma unroll
+    for (int j = 0; j <= PAD; ++j) {  // symmetric taps: PAD + 1 distinct values, wave-uniform -> scalar registers
+      const double t = rc[j];
+      h[j] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)), __builtin_amdgcn_readfirstlane(__double2loint(t)));
+    }
+#pragma unroll
+    for (int w = 0; w < CV + 2 * PAD; ++w) {
+      int idx = m0 - PAD + w;
+      idx = idx < 0 ? 0 : (idx >= n_re ? n_re - 1 : idx);  // clamped reads only feed outputs the last wave overwrites
+      const float2 x = Pl[idx];
+      const double dx = (double)x.x, dy = (double)x.y;
+#pragma unroll
+      for (int o = 0; o < CV; ++o) {
+        const int j = o + 2 * PAD - w;
+        if (j >= 0 && j < NTAP) {
+          ar[o] += h[j <= PAD ? j : 2 * PAD - j] * dx;
+          ai[o] += h[j <= PAD ? j : 2 * PAD - j] * dy;
+        }
+      }
+      // keep at most a few window samples in flight: unfenced, the scheduler hoists all CV+2*PAD LDS reads
+      // (2 VGPRs each) above the first MAC
+      if ((w & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  if (tid < NCV) {
+#pragma unroll
+    for (int o = 0; o < CV; ++o) {
+      const int m = m0 + o;
+      if (m >= PAD && m < n_re - PAD) Pl[m] = make_float2((float)ar[o], (float)ai[o]);
+    }
+  } else if (em >= 0) {
+    Pl[em] = make_float2((float)er, (float)ei);
+  }
+  __syncthreads();
+}
+
+// L layers, NH hops; ND = DM-RS symbols per hop whose pilot REs (and pilots) stay in registers between the CFO,
+// LS and residual stages (needs one CDM group and n_re <= KPT*NT); ND = 0 re-reads them from global memory
+// (L2) in each of the three stages and works for any geometry.
 template <int L, int NH, int ND>
 __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
                                                          const uint16_t* __restrict__ re_idx,
@@ -558,67 +648,12 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
       const int n_pils = plan->n_pils, rc_len = plan->rc_len;
       const int pad = rc_len / 2;
       const double vmx = plan->vp_mx, vin = plan->vp_inv_n, vid = plan->vp_inv_denom;
-      if (plan->filt_windowed) {
-        // Sliding-window FIR: conv(x, rc, "same") of [virtual head ; P ; virtual tail] cropped back to P
-        // (T:649-664).  Threads 0..NT-65 own CE_CONV_C consecutive outputs and accumulate the taps that hit
-        // real pilots (float64 MACs, T:477-490) while the last wave fits the virtual pilots; after one
-        // barrier the few threads whose window reaches past a band edge add the virtual-pilot taps.
-        constexpr int CV = CE_CONV_C, NCV = NT - 64;
+      if (plan->filt_windowed) {  // host sets it only for the 15-tap filter; other lengths take the generic form
         float2* vpb = scratch;  // [2][16]: virtual pilot at distance e+1 beyond the head / tail edge
-        const int m0 = tid * CV;
-        const int nw = CV + 2 * pad;
 #pragma unroll 1
         for (int l = 0; l < L; ++l) {
           float2* Pl = Ph + l * n_re_pad;
-          double ar[CV], ai[CV];
-#pragma unroll
-          for (int o = 0; o < CV; ++o) ar[o] = ai[o] = 0.0;
-          if (tid >= NCV) {
-            if (tid - NCV < 32) {
-              const int e = (tid - NCV) >> 4;
-              virtual_pilots(Pl, n_re, n_pils, e != 0, (tid - NCV) & 15, vmx, vin, vid,
-                             [&](int dist, float2 val) { vpb[e * 16 + dist] = val; });
-            }
-          } else if (m0 < n_re) {
-            for (int w = 0; w < nw; ++w) {
-              const int idx = m0 - pad + w;
-              if (idx >= 0 && idx < n_re) {
-                const float2 x = Pl[idx];
-                const double dx = (double)x.x, dy = (double)x.y;
-                const double* hz = rcz + (2 * pad + CV - 1 - w);  // taps for outputs o = 0..CV-1
-#pragma unroll
-                for (int o = 0; o < CV; ++o) {
-                  ar[o] += hz[o] * dx;
-                  ai[o] += hz[o] * dy;
-                }
-              }
-            }
-          }
-          __syncthreads();
-          if (tid < NCV && m0 < n_re) {
-            if (m0 - pad < 0 || m0 + CV - 1 + pad >= n_re) {
-              for (int w = 0; w < nw; ++w) {
-                const int idx = m0 - pad + w;
-                int vi = -1;
-                if (idx < 0 && -1 - idx < n_pils) vi = -1 - idx;                      // head, distance -idx
-                else if (idx >= n_re && idx - n_re < n_pils) vi = 16 + (idx - n_re);  // tail
-                if (vi >= 0) {
-                  const float2 x = vpb[vi];
-                  const double dx = (double)x.x, dy = (double)x.y;
-                  const double* hz = rcz + (2 * pad + CV - 1 - w);
-#pragma unroll
-                  for (int o = 0; o < CV; ++o) {
-                    ar[o] += hz[o] * dx;
-                    ai[o] += hz[o] * dy;
-                  }
-                }
-              }
-            }
-#pragma unroll
-            for (int o = 0; o < CV; ++o)
-              if (m0 + o < n_re) Pl[m0 + o] = make_float2((float)ar[o], (float)ai[o]);
-          }
-          __syncthreads();
+          smooth_windowed<7>(Pl, n_re, n_pils, pad, rcz, vpb, tid, vmx, vin, vid);  // 15 taps: >= 3 PRB, comb 2
         }
       } else {
         // generic form (very wide bands): copy [virtual ; P ; virtual] to the scratch, one output per thread
@@ -851,7 +886,15 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
 
   STAMP(8);
 #if CE_PERSIST
-  if (wg + gridDim.x < a.n_items) load_hop(item_of(wg + gridDim.x, a.n_ports, a.n_items), 0);  // prefetch for the next trip
+  {
+    // Prefetch the next item's pilots; they are consumed at the top of the next trip.  The index is tied
+    // (empty asm) to an LDS value that only exists after the epilogue's barrier, so the scheduler cannot hoist
+    // these 28 loads above the TA stage, where their 56 destination registers would not fit.
+    int64_t nxt = wg + gridDim.x;
+    const float dep = rot_final[0].x;
+    asm volatile("" : "+s"(nxt) : "v"(dep));
+    if (nxt < a.n_items) load_hop(item_of(nxt, a.n_ports, a.n_items), 0);
+  }
 #endif
   // ---------------------------------------------------------------- interpolate + replicate + CFO ramp (S10)
   const int n_sym = plan->n_sym;

@@ -3,7 +3,7 @@
 
 Usage: python tools/ablate.py [--slots 8192] [--ports 4] [--smoothing filter] name=flags ...
 e.g.   python tools/ablate.py full= nota=-DCE_ABLATE=1 nowr=-DCE_ABLATE=8
-Rebuilds csrc/libce_hip.so per variant in a subprocess (fresh process per variant so the
+Builds /tmp/libce_hip_ablate.so per variant and runs it in a subprocess (fresh process per variant so the
 library is reloaded), prints ms per launch and achieved algorithmic GB/s."""
 import argparse, json, subprocess, sys, os
 from pathlib import Path
@@ -38,10 +38,13 @@ def main():
     csrc = ROOT / "srsran_ce_pytorch_amd" / "csrc"
     for v in a.variants:
         name, _, flags = v.partition("=")
+        flags, _, ksrc = flags.partition("@")          # name=flags@kernel_source (default: the tree's ce_kernels.hip)
+        kfile = str(ROOT / ksrc) if ksrc else str(csrc / "ce_kernels.hip")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT/'include'}", f"-I{csrc}",
-               "-o", str(csrc / "libce_hip.so"), str(csrc / "ce_api.hip"), str(csrc / "ce_kernels.hip")] + flags.split()
+               "-o", "/tmp/libce_hip_ablate.so", str(csrc / "ce_api.hip"), kfile] + flags.split()
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-        r = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), a.slots, a.ports, a.smoothing, a.layers)], capture_output=True, text=True)  # stderr (compiler warnings) dropped
+        r = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), a.slots, a.ports, a.smoothing, a.layers)], capture_output=True, text=True,
+                           env=dict(os.environ, CE_HIP_LIB="/tmp/libce_hip_ablate.so"))   # never touches the shipped library  # stderr (compiler warnings) dropped
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         print(f"{name:12s} {flags:28s} {line[-1] if line else r.stderr[-400:]}", flush=True)
 

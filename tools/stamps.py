@@ -9,7 +9,9 @@ sys.path.insert(0, str(ROOT))
 csrc = ROOT / "srsran_ce_pytorch_amd" / "csrc"
 flags = sys.argv[1:] 
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT/'include'}", f"-I{csrc}", "-DCE_STAMPS=1",
-                "-o", str(csrc / "libce_hip.so"), str(csrc / "ce_api.hip"), str(csrc / "ce_kernels.hip")] + flags, check=True)
+                "-o", "/tmp/libce_hip_stamps.so", str(csrc / "ce_api.hip"), str(csrc / "ce_kernels.hip")] + flags, check=True)
+import os
+os.environ["CE_HIP_LIB"] = "/tmp/libce_hip_stamps.so"      # never overwrite the shipped library with a diagnostic build
 import torch
 from srsran_ce_pytorch_amd import estimator as E, synth as S, _lib
 lib = _lib.load()
@@ -32,3 +34,5 @@ for slots, ports in [(64, 4), (8192, 4)]:
     d = np.diff(t[:, :11], axis=1)
     print(f"--- {n} items: median us per stage (total {np.median(t[:,10]-t[:,0]):.1f} us; kernel span {(t[:,10].max()-t[:,0].min()):.0f} us)")
     print("  ".join(f"{nm}={np.median(d[:, i]):.2f}" for i, nm in enumerate(names[1:])))
+    if t[:, 11].max() > 0:
+        print(f"  smoothing detail: conv-phase1 done (wave 0) +{np.median(t[:,11]-t[:,4]):.2f}  virtual pilots done (wave 3) +{np.median(t[:,12]-t[:,4]):.2f}  after barrier +{np.median(t[:,13]-t[:,4]):.2f}  stage end +{np.median(t[:,5]-t[:,4]):.2f}")
