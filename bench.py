@@ -11,6 +11,8 @@ Workloads (BASELINE.json configs):
                         reference's own frequency smoothing (it has no MMSE/Wiener mode).
                         This is the configuration the metric ("273-PRB PUSCH, 4 Rx") is quoted on.
   pusch273_1rx_none     configs[1]: LS + linear interpolation, 273 PRB / 1 Rx / 1024 slots.
+  pusch273_4rx_cnn      configs[4]: the ce_dl_cnn.py variant (fixed-weight 1-D in-painting instead of linear
+                        interpolation; the reference has no Conv2d / fp16 / learned weights).
 
 Prints ONE JSON line on rank 0 with the driver's fields plus ``roofline`` (HBM; algorithmic bytes
 per launch / HIP-event launch time) and, at N=1, ``cpu_baseline`` (the CPU oracle = a port of the
@@ -33,12 +35,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 WORKLOADS = {
     "pusch273_4rx_filter": dict(smoothing="filter", ports=4, slots=8192),
     "pusch273_1rx_none": dict(smoothing="none", ports=1, slots=1024),
+    # configs[4] as the reference actually implements it: ce_dl_cnn's fixed 3-tap in-painting
+    "pusch273_4rx_cnn": dict(smoothing="filter", ports=4, slots=8192, interp="cnn"),
 }
 
 
 def _cpu_worker(args):
     """Oracle (CPU port of the reference algorithm) on one slot's ports, repeated; returns items done."""
-    case, n_ports, reps, seed = args
+    case, n_ports, reps, seed, interp = args
     sys.path.insert(0, str(ROOT / "oracle"))
     import ce_oracle as O
     from srsran_ce_pytorch_amd import synth as S
@@ -46,33 +50,33 @@ def _cpu_worker(args):
     b = S.build_case(dict(case, seed=seed), n_ports)
     for _ in range(2):                                                  # untimed warm-up (page faults, caches)
         for r in range(n_ports):
-            O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+            O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=interp)
     t0 = time.perf_counter()
     for _ in range(reps):
         for r in range(n_ports):
-            O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+            O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=interp)
     return reps * n_ports, time.perf_counter() - t0
 
 
-def cpu_baseline(case, n_ports, target_core_seconds=20.0):
+def cpu_baseline(case, n_ports, target_core_seconds=20.0, interp="linear"):
     """Bounded sample of the same workload on the host cores (fork happens BEFORE any GPU init)."""
     import multiprocessing as mp
 
     cores = min(16, len(os.sched_getaffinity(0)))
-    n1, t1 = _cpu_worker((case, n_ports, 3, 999))                 # per-item estimate on one core
+    n1, t1 = _cpu_worker((case, n_ports, 3, 999, interp))         # per-item estimate on one core
     per_item = t1 / n1
     reps = max(1, int(target_core_seconds / cores / (per_item * n_ports)))
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(case, n_ports, reps, 1000 + i) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(case, n_ports, reps, 1000 + i, interp) for i in range(cores)])
     wall = time.perf_counter() - t0
     items = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
     slots = items / n_ports
     return dict(value=slots / busy, unit="slots/s", cores=cores, kind="port",
                 sample=f"{int(slots)} slots x {n_ports} ports of the same 273-PRB workload through oracle/ce_oracle.py "
-                       f"(numpy port of ce_rule_tensorized), {cores} worker processes, {busy:.1f} s busy / {wall:.1f} s wall; "
+                       f"(numpy port of {'ce_dl_cnn' if interp == 'cnn' else 'ce_rule_tensorized'}), {cores} worker processes, {busy:.1f} s busy / {wall:.1f} s wall; "
                        f"{per_item * 1e3:.2f} ms per slot-port on one core")
 
 
@@ -101,7 +105,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(case, n_ports)                           # before any GPU initialisation (forks)
+        cpu = cpu_baseline(case, n_ports, interp=wl.get("interp", "linear"))   # before any GPU initialisation (forks)
 
     import torch
     import torch.distributed as dist
@@ -115,7 +119,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     hop1, hop2, cfg = S.numpy_hops(case)
-    plan = E.make_plan(hop1, hop2, cfg, case["beta"], 1, case["n_prb_grid"], case["n_sym"], dev)
+    plan = E.make_plan(hop1, hop2, cfg, case["beta"], 1, case["n_prb_grid"], case["n_sym"], dev, wl.get("interp", "linear"))
     rx, pilots = S.torch_inputs(case, n_slots, n_ports, dev, seed=1234 + rank)
     out = E.estimate_with_plan(plan, rx, pilots)                    # allocates the outputs once
     torch.cuda.synchronize()
@@ -160,7 +164,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "n_prb": 273, "n_sc": plan.n_sc, "n_sym": plan.n_sym, "dmrs_symbols": [2, 11],
-                   "layers": 1, "rx_ports": n_ports, "smoothing": wl["smoothing"], "slots_per_gpu": n_slots,
+                   "layers": 1, "rx_ports": n_ports, "smoothing": wl["smoothing"], "interp": wl.get("interp", "linear"), "slots_per_gpu": n_slots,
                    "global_slots": world * n_slots, "rx_layout": "[slot][port][sym][sc]", "parallelism": f"slot-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -32,7 +32,8 @@ extern "C" {
 
 /* config.Smoothing (T:633-668) */
 enum { CE_SMOOTH_NONE = 0, CE_SMOOTH_MEAN = 1, CE_SMOOTH_FILTER = 2 };
-/* frequency interpolation: T:311-340 (linear) or src/ce_dl_cnn.py:292-295 (3-tap in-painting) */
+/* frequency interpolation: T:311-340 (linear) or src/ce_dl_cnn.py:276-295, 473-508 (fixed 3-tap partial-convolution
+ * in-painting + two low-pass passes; also enables the CNNSmoothingAlpha blend of src/ce_dl_cnn.py:712-715) */
 enum { CE_INTERP_LINEAR = 0, CE_INTERP_CNN = 1 };
 
 enum {

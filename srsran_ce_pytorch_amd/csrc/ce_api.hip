@@ -87,7 +87,8 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
     return fail(CE_ERR_UNSUPPORTED, "grid of %d PRB: the time-alignment IFFT (T:679) needs 12*n_prb <= %d", d->n_prb_grid, CE_FFT_SIZE);
   if (d->n_sym < 1 || d->n_sym > CE_MAX_SYMBOLS) return fail(CE_ERR_UNSUPPORTED, "n_sym=%d outside 1..%d", d->n_sym, CE_MAX_SYMBOLS);
   if (d->smoothing < CE_SMOOTH_NONE || d->smoothing > CE_SMOOTH_FILTER) return fail(CE_ERR_INVALID, "Unknown smoothing strategy %d.", d->smoothing);
-  if (d->interp != CE_INTERP_LINEAR) return fail(CE_ERR_UNSUPPORTED, "interp=%d: only linear interpolation is built", d->interp);
+  if (d->interp != CE_INTERP_LINEAR && d->interp != CE_INTERP_CNN) return fail(CE_ERR_INVALID, "unknown interp %d", d->interp);
+  if (d->interp == CE_INTERP_CNN && d->n_sym != CE_MAX_SYMBOLS) return fail(CE_ERR_UNSUPPORTED, "the in-painting path is built for 14-symbol grids");
   if (!(d->scs_hz > 0) || !(d->beta_dmrs > 0)) return fail(CE_ERR_INVALID, "scs and beta_dmrs must be positive");
 
   ce_plan* p = new (std::nothrow) ce_plan();
@@ -160,6 +161,7 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
       const int dpp = popcount12(m);
       if (dpp == 0) { delete p; return fail(CE_ERR_INVALID, "hop %d: DMRSREmask column %d is empty", h, c); }
       H.dpp[c] = dpp;
+      H.mask12 |= m << (16 * c);
       H.div_magic[c] = (uint32_t)(0x100000000ull / (unsigned)dpp) + 1u;
       {
         uint64_t pos = 0, ord = 0;
@@ -272,6 +274,21 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
     int lg = 8;
     while (lg < 12 && P.n_hops * L * (2 << lg) * 8 <= need) ++lg;
     P.wr_ch_log2 = lg;
+    if (d->interp == CE_INTERP_CNN) {
+      // whole-band H rows for every (hop, layer) + a second x buffer + two mask byte arrays
+      int n_max = 0;
+      for (int h = 0; h < d->n_hops; ++h) n_max = P.hop[h].n_sc_hop > n_max ? P.hop[h].n_sc_hop : n_max;
+      P.cnn_n_max = n_max;
+      P.cnn_h_stride = (n_sc + 1) & ~1;
+      const int h_bytes = P.n_hops * L * P.cnn_h_stride * 8;
+      P.cnn_pong_off = h_bytes;
+      P.cnn_m_off = h_bytes + ((n_max + 1) & ~1) * 8;
+      const int cnn_need = P.cnn_m_off + 2 * ((n_max + 15) & ~15);
+      if (cnn_need > P.scratch_bytes) P.scratch_bytes = cnn_need;
+      double a = d->cnn_smoothing_alpha;
+      P.cnn_alpha = (float)(a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a));
+      for (int c = 0; c < 5; ++c) P.cnn_rcp[c] = 1.0 / (0.25 * c + 1e-12);
+    }
   }
   // register path: every hop has the same 1 or 2 DM-RS symbols, one CDM group, band fits CE_KPT per thread
   P.reg_nd = 0;

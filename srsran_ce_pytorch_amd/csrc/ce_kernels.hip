@@ -278,6 +278,80 @@ __device__ __forceinline__ int pilot_sc(const CeDevHop& hp, const uint16_t* __re
   return re_idx[hp.re_off[c] + k];
 }
 
+// ---- src/ce_dl_cnn.py's fixed-weight stencil (C:433-508), the reference's alternative to linear interpolation ----
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// one pass of the [.25 .5 .25] stencil with reflect padding at index i, float64 (C:433-451)
+__device__ __forceinline__ void lp3(const float2* x, int i, int n, double* yr, double* yi) {
+  const float2 a = x[reflect_idx(i - 1, n)], b = x[i], c = x[reflect_idx(i + 1, n)];
+  *yr = (0.25 * (double)a.x + 0.5 * (double)b.x) + 0.25 * (double)c.x;
+  *yi = (0.25 * (double)a.y + 0.5 * (double)b.y) + 0.25 * (double)c.y;
+}
+
+// two passes (C:454-470): y2[i] = stencil(y1)[i], y1 = stencil(x), each pass with its own reflect padding
+__device__ __forceinline__ float2 lp3x2(const float2* x, int i, int n) {
+  double r[3], q[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) lp3(x, reflect_idx(i - 1 + d, n), n, &r[d], &q[d]);
+  return make_float2((float)((0.25 * r[0] + 0.5 * r[1]) + 0.25 * r[2]), (float)((0.25 * q[0] + 0.5 * q[1]) + 0.25 * q[2]));
+}
+
+// Partial-convolution in-painting of one layer over a hop band of n subcarriers (C:473-508, C:276-295).
+// x lives in LDS (ping-pong between `dst` and `pong`), the fill mask m in two byte arrays.  The loop stops
+// early at a bitwise fixed point (x and m unchanged), after which every further reference iteration is the
+// identity -- the comb-2 DM-RS reaches it after two iterations instead of max(6, n/8).  num/(den+eps) is
+// evaluated as num * (1/(den+eps)) with the five possible reciprocals tabulated (<= 1 ulp in float64
+// before the float32 round trip).  Result ends in `dst`.
+__device__ void cnn_inpaint_layer(float2* dst, float2* pong, unsigned char* m_a, unsigned char* m_b, const float2* Pl,
+                                  int n, unsigned mask12, int dpp, int n_iters, const double* rcp, int tid) {
+  for (int i = tid; i < n; i += NT) {
+    const int q = i / 12, r = i - 12 * q;
+    const bool known = (mask12 >> r) & 1u;
+    dst[i] = known ? Pl[q * dpp + __popc(mask12 & ((1u << r) - 1u))] : make_float2(0.f, 0.f);
+    m_a[i] = known ? 1 : 0;
+  }
+  __syncthreads();
+  float2 *cur = dst, *nxt = pong;
+  if (dpp < 12) {  // known_mask.all() skips the in-painting (C:487-488)
+    unsigned char *mc = m_a, *mn = m_b;
+#pragma unroll 1
+    for (int it = 0; it < n_iters; ++it) {
+      int changed = 0;
+      for (int i = tid; i < n; i += NT) {
+        const int il = reflect_idx(i - 1, n), ir = reflect_idx(i + 1, n);
+        const float2 b = cur[i];
+        const int mb = mc[i], code = mc[il] + 2 * mb + mc[ir];
+        const int q = i / 12, r = i - 12 * q;
+        float2 xn = b;
+        if (!((mask12 >> r) & 1u)) {
+          const float2 a = cur[il], c = cur[ir];
+          const double w = rcp[code];
+          xn = make_float2((float)(((0.25 * (double)a.x + 0.5 * (double)b.x) + 0.25 * (double)c.x) * w),
+                           (float)(((0.25 * (double)a.y + 0.5 * (double)b.y) + 0.25 * (double)c.y) * w));
+        }
+        const int mnew = mb | (code > 0);
+        changed |= (__float_as_uint(xn.x) != __float_as_uint(b.x)) | (__float_as_uint(xn.y) != __float_as_uint(b.y)) | (mnew != mb);
+        nxt[i] = xn;
+        mn[i] = (unsigned char)mnew;
+      }
+      const int any = __syncthreads_or(changed);
+      float2* t = cur; cur = nxt; nxt = t;
+      unsigned char* u = mc; mc = mn; mn = u;
+      if (!any) break;
+    }
+  }
+  // low-pass twice; known pilots are restored unless every RE is a pilot (C:487-488, C:507-508)
+  for (int i = tid; i < n; i += NT) {
+    const int q = i / 12, r = i - 12 * q;
+    nxt[i] = (dpp < 12 && ((mask12 >> r) & 1u)) ? cur[i] : lp3x2(cur, i, n);
+  }
+  __syncthreads();
+  if (nxt != dst) {
+    for (int i = tid; i < n; i += NT) dst[i] = nxt[i];
+    __syncthreads();
+  }
+}
+
 // RC FIR over one layer's pilots, in place: conv([virtual head ; P ; virtual tail], rc, "same") cropped back
 // to P (T:649-664), float64 MACs (T:477-490).  PAD = len(rc) / 2 (the 31-tap instantiation also serves shorter
 // odd lengths through zero taps).  Waves 0..2: each thread owns CE_CONV_C consecutive outputs and slides a
@@ -691,6 +765,27 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
           __syncthreads();
         }
       }
+      if (plan->interp == CE_INTERP_CNN && plan->cnn_alpha > 0.f) {
+        // optional blend with one low-pass pass over the smoothed pilots (src/ce_dl_cnn.py:712-715)
+        const float al = plan->cnn_alpha;
+#pragma unroll 1
+        for (int l = 0; l < L; ++l) {
+          float2* Pl = Ph + l * n_re_pad;
+          for (int k = tid; k < n_re; k += NT) {
+            const float2 rcv = Pl[k];
+            float2 sm = rcv;
+            if (n_re > 2) {
+              double yr, yi;
+              lp3(Pl, k, n_re, &yr, &yi);
+              sm = make_float2((float)yr, (float)yi);
+            }
+            scratch[k] = make_float2(rcv.x + al * (sm.x - rcv.x), rcv.y + al * (sm.y - rcv.y));
+          }
+          __syncthreads();
+          for (int k = tid; k < n_re; k += NT) Pl[k] = scratch[k];
+          __syncthreads();
+        }
+      }
     }
 
     STAMP(5);
@@ -944,7 +1039,38 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
       rsel[e] = h < 0 ? make_float2(0.f, 0.f) : rot_final[sym];  // rot_final == 1 when no CFO ramp applies
     }
     float4* out4 = reinterpret_cast<float4*>(out);
-    if constexpr (SC_STEP % 12 == 0) {
+    if (plan->interp == CE_INTERP_CNN) {
+      // in-painted response for every (hop, layer), whole band at once, then the same phase-owning store loop
+      const int hs = plan->cnn_h_stride, n_sc = plan->n_sc;
+      float2* pong = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(scratch) + plan->cnn_pong_off);
+      unsigned char* m_a = reinterpret_cast<unsigned char*>(scratch) + plan->cnn_m_off;
+      unsigned char* m_b = m_a + ((plan->cnn_n_max + 15) & ~15);
+#pragma unroll 1
+      for (int hl = 0; hl < NH * L; ++hl) {
+        const int h = hl / L, l = hl - h * L;
+        const CeDevHop& hp = plan->hop[h];
+        float2* row = scratch + hl * hs;
+        for (int i = tid; i < n_sc; i += NT)
+          if (i < hp.sc0 || i >= hp.sc0 + hp.n_sc_hop) row[i] = make_float2(0.f, 0.f);
+        const int c = l >> 1;
+        const unsigned mask12 = (unsigned)((hp.mask12 >> (16 * c)) & 0xFFFu);
+        const int n_it = hp.n_sc_hop / 8 > 6 ? hp.n_sc_hop / 8 : 6;  // C:293
+        cnn_inpaint_layer(row + hp.sc0, pong, m_a, m_b, P + (h * L + l) * n_re_pad, hp.n_sc_hop, mask12, hp.dpp[c], n_it,
+                          plan->cnn_rcp, tid);
+      }
+      __syncthreads();
+      const float2* HA = scratch + (hsel[0] * L + lsel[0]) * hs;
+      const float2* HB = scratch + (hsel[1] * L + lsel[1]) * hs;
+      if (tid < ACTIVE) {
+        float4* o = out4 + tid;
+#pragma unroll 4
+        for (int s = sc_lane; s < n_sc; s += SC_STEP) {
+          const float2 ya = cmul(HA[s], rsel[0]), yb = cmul(HB[s], rsel[1]);
+          store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
+          o += ACTIVE;
+        }
+      }
+    } else if constexpr (SC_STEP % 12 == 0) {
       // Direct form (L = 1, 3): a thread's subcarriers advance by whole PRBs, so its RE position inside the
       // PRB -- hence its interpolation weight and anchor ordinals (T:325-337) -- is constant: interpolate
       // straight from P in LDS, no staging buffer, no barrier.

@@ -38,6 +38,8 @@ struct CeDevHop {
   uint64_t pos_packed[CE_MAX_CDM];    // 4 bits per pilot j of a PRB: its RE position
   uint64_t ord_packed;                // last CDM group: 4 bits per RE r: pilot ordinal inside the PRB, 15 = not a pilot
   uint64_t ta_res_packed;             // 4 bits per entry of ta_res
+  uint32_t mask12;                    // DMRSREmask columns: bits 0-11 CDM group 0, bits 16-27 CDM group 1
+  uint32_t pad1;
 };
 
 struct CeDevPlan {
@@ -53,6 +55,13 @@ struct CeDevPlan {
   double rcz[CE_RCZ_LEN];             // the same taps with CE_CONV_C-1 zeros on both sides (windowed FIR)
   double vp_mx, vp_inv_n, vp_inv_denom;  // regression constants of the n_pils-point straight-line fit (T:105-117)
   int32_t filt_windowed, pad1;        // 1: n_re <= (CE_THREADS-64)*CE_CONV_C -> sliding-window FIR
+  // ce_dl_cnn.py in-painting (interp == CE_INTERP_CNN): whole-band H per (hop, layer) in the scratch
+  int32_t cnn_h_stride;               // complex elements between consecutive (hop, layer) H rows (= n_sc)
+  int32_t cnn_pong_off, cnn_m_off;    // byte offsets inside the scratch: second x buffer, two mask byte arrays
+  int32_t cnn_n_max;                  // longest hop band (subcarriers)
+  float cnn_alpha;                    // clamp(CNNSmoothingAlpha, 0, 1) (src/ce_dl_cnn.py:712-715)
+  int32_t pad2;
+  double cnn_rcp[5];                  // 1 / (code/4 + 1e-12), code = m[i-1] + 2 m[i] + m[i+1] (src/ce_dl_cnn.py:498-501)
   CeDevHop hop[CE_MAX_HOPS];
 };
 

@@ -22,7 +22,7 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run_items(fx_like, grids, layout, pilots=None):
+def _run_items(fx_like, grids, layout, pilots=None, interp="linear"):
     """Run all items of a case as the Rx ports of one slot.  layout 'ref' = [.., sc, sym] dense
     (the reference's), 'sym_major' = [.., sym, sc] buffer viewed as [.., sc, sym]."""
     dev = _dev()
@@ -30,7 +30,7 @@ def _run_items(fx_like, grids, layout, pilots=None):
     if layout == "sym_major":
         g = g.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
     p = torch.as_tensor(fx_like.pilots if pilots is None else pilots, device=dev)
-    out = E.estimate(g, p, fx_like.beta, fx_like.hop1, fx_like.hop2, fx_like.config)
+    out = E.estimate(g, p, fx_like.beta, fx_like.hop1, fx_like.hop2, fx_like.config, interp=interp)
     torch.cuda.synchronize()
     ch = out[0][0].cpu().numpy()
     sc = [t[0].cpu().numpy() if t.numel() else None for t in out[1:]]
@@ -45,6 +45,28 @@ def test_hip_matches_reference_fixture(name, layout):
     for it in range(fx.grids.shape[0]):
         got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], np.nan if sc[4] is None else sc[4][it]]
         check_outputs(ch[it], got, fx.ref_ch_est[it], fx.ref_scalars[it], TOL_CH, TOL_SC, f"{name}[{it}]/{layout}")
+
+
+@pytest.mark.parametrize("name", golden_names("C"))
+def test_hip_cnn_variant_matches_reference_fixture(name):
+    """interp="cnn": the fixed-weight in-painting of src/ce_dl_cnn.py (fixtures from the real ce_dl_cnn)."""
+    fx = load_fixture(name)
+    ch, sc = _run_items(fx, fx.grids, "sym_major", interp="cnn")
+    for it in range(fx.grids.shape[0]):
+        got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], np.nan if sc[4] is None else sc[4][it]]
+        check_outputs(ch[it], got, fx.ref_ch_est[it], fx.ref_scalars[it], TOL_CH, TOL_SC, f"{name}[{it}]/cnn")
+
+
+def test_hip_cnn_variant_random_vs_oracle():
+    """Sparse (type-2) mask over a wide band: the in-painting needs many iterations; 2 layers; alpha blend."""
+    case = S.case_spec("cnn_rnd", 106, [S.hop_spec([2, 11], 3, 100, re_masks=[S.TYPE2_CDM0])], n_layers=2, scs=15e3, seed=301)
+    b = S.build_case(case, 2)
+    b.config.CNNSmoothingAlpha = 0.4
+    ch, sc = _run_items(b, b.grids, "ref", interp="cnn")
+    for it in range(2):
+        ref = O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp="cnn")
+        got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], sc[4][it]]
+        check_outputs(ch[it], got, ref[0], list(ref[1:]), TOL_CH, TOL_SC, f"cnn_rnd[{it}]")
 
 
 RANDOM_CASES = [
