@@ -88,6 +88,23 @@ typedef struct ce_plan_info {
   int64_t pilot_bytes_per_slot; /* n_re*n_dmrs*L*8 */
 } ce_plan_info;
 
+/* What ce_plan_create derives on the host, for inspection and CPU-only tests. */
+typedef struct ce_plan_host_view {
+  int32_t n_re, n_dmrs_total, n_pils, rc_len;   /* n_pils, len(rcFilter): T:638-647 */
+  int32_t reg_nd, lds_bytes, scratch_bytes, filt_windowed, cfo_estimated, reserved;
+  int32_t ta_nres[CE_MAX_HOPS], contig[CE_MAX_HOPS];
+  int32_t last_idx[CE_MAX_HOPS][CE_MAX_CDM];     /* last pilot RE of the hop band (T:314) */
+  int32_t r_ord[CE_MAX_HOPS][CE_MAX_CDM][12];    /* right-anchor ordinal inside the PRB per RE (T:325) */
+  float alpha[CE_MAX_HOPS][CE_MAX_CDM][12];      /* interpolation weight per RE (T:333-337) */
+  double rc[31];                                  /* raised-cosine taps, unit sum (T:184-234) */
+  double sst[CE_MAX_SYMBOLS];                     /* symbolStartTime (T:809-820) */
+  double two_pi_nsamples[CE_MAX_HOPS];            /* 2*pi*nSamples (T:418-426) */
+  double n_pilots, noise_den;                     /* T:901-915 */
+} ce_plan_host_view;
+
+/* Same validation and float64 derivation as ce_plan_create but touches no GPU: usable on a CPU-only host. */
+int ce_plan_derive_host(const ce_plan_desc* desc, ce_plan_host_view* view);
+
 /* Validates the descriptor, derives every per-plan table on the host in float64 (pilot RE index
  * lists T:571-576, symbol start times T:809-820, CFO sample span T:418-426, RC taps T:184-234,
  * interpolation anchors T:311-338, IFFT twiddles) and uploads them.  Synchronous; not for the

@@ -44,8 +44,20 @@ class PlanInfo(C.Structure):
                 ("pilot_bytes_per_slot", C.c_int64)]
 
 
-EXPORTS = ["ce_plan_create", "ce_plan_destroy", "ce_plan_get_info", "ce_estimate_batch", "ce_time_batch",
-           "ce_last_error", "ce_abi_version"]
+class PlanHostView(C.Structure):
+    _fields_ = [("n_re", C.c_int32), ("n_dmrs_total", C.c_int32), ("n_pils", C.c_int32), ("rc_len", C.c_int32),
+                ("reg_nd", C.c_int32), ("lds_bytes", C.c_int32), ("scratch_bytes", C.c_int32), ("filt_windowed", C.c_int32),
+                ("cfo_estimated", C.c_int32), ("reserved", C.c_int32),
+                ("ta_nres", C.c_int32 * CE_MAX_HOPS), ("contig", C.c_int32 * CE_MAX_HOPS),
+                ("last_idx", (C.c_int32 * CE_MAX_CDM) * CE_MAX_HOPS),
+                ("r_ord", ((C.c_int32 * 12) * CE_MAX_CDM) * CE_MAX_HOPS),
+                ("alpha", ((C.c_float * 12) * CE_MAX_CDM) * CE_MAX_HOPS),
+                ("rc", C.c_double * 31), ("sst", C.c_double * CE_MAX_SYMBOLS), ("two_pi_nsamples", C.c_double * CE_MAX_HOPS),
+                ("n_pilots", C.c_double), ("noise_den", C.c_double)]
+
+
+EXPORTS = ["ce_plan_create", "ce_plan_destroy", "ce_plan_get_info", "ce_plan_derive_host", "ce_estimate_batch",
+           "ce_time_batch", "ce_last_error", "ce_abi_version"]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -82,6 +94,8 @@ def load() -> C.CDLL:
     lib.ce_plan_destroy.restype = None
     lib.ce_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
     lib.ce_plan_get_info.restype = C.c_int
+    lib.ce_plan_derive_host.argtypes = [C.POINTER(PlanDesc), C.POINTER(PlanHostView)]
+    lib.ce_plan_derive_host.restype = C.c_int
     batch = [vp, vp, i64p, vp, i64p, C.c_int64, C.c_int32, vp, dp, dp, dp, dp, dp, vp]
     lib.ce_estimate_batch.argtypes = batch
     lib.ce_estimate_batch.restype = C.c_int

@@ -77,7 +77,7 @@ extern "C" {
 const char* ce_last_error(void) { return g_err.c_str(); }
 int ce_abi_version(void) { return CE_ABI_VERSION; }
 
-int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
+static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (!d || !out) return fail(CE_ERR_INVALID, "null argument");
   *out = nullptr;
   if (d->abi_version != CE_ABI_VERSION) return fail(CE_ERR_INVALID, "ABI version %d != %d", d->abi_version, CE_ABI_VERSION);
@@ -315,6 +315,10 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
     tw[m] = make_float2((float)cos(a), (float)sin(a));
   }
 
+  if (!upload) {  // host-only derivation (ce_plan_derive_host): no HIP call at all
+    *out = p;
+    return CE_OK;
+  }
   hipError_t e = hipSetDevice(d->device);
   if (e == hipSuccess) e = hipMalloc(&p->dev_plan, sizeof(CeDevPlan));
   if (e == hipSuccess) e = hipMalloc(&p->dev_re_idx, re_idx.size() * sizeof(uint16_t));
@@ -334,6 +338,34 @@ int ce_plan_create(const ce_plan_desc* d, ce_plan** out) {
     return CE_ERR_HIP;
   }
   *out = p;
+  return CE_OK;
+}
+
+int ce_plan_create(const ce_plan_desc* d, ce_plan** out) { return plan_build(d, out, true); }
+
+int ce_plan_derive_host(const ce_plan_desc* d, ce_plan_host_view* v) {
+  if (!v) return fail(CE_ERR_INVALID, "null argument");
+  ce_plan* p = nullptr;
+  const int rc = plan_build(d, &p, false);
+  if (rc != CE_OK) return rc;
+  const CeDevPlan& P = p->host;
+  memset(v, 0, sizeof(*v));
+  v->n_re = P.n_re; v->n_dmrs_total = p->info.n_dmrs_total; v->n_pils = P.n_pils; v->rc_len = P.rc_len;
+  v->reg_nd = P.reg_nd; v->lds_bytes = p->info.lds_bytes; v->scratch_bytes = P.scratch_bytes;
+  v->filt_windowed = P.filt_windowed; v->cfo_estimated = P.cfo_estimated;
+  v->n_pilots = P.n_pilots; v->noise_den = P.noise_den;
+  for (int i = 0; i < CE_MAX_RC_TAPS; ++i) v->rc[i] = P.rc[i];
+  for (int i = 0; i < CE_MAX_SYMBOLS; ++i) v->sst[i] = P.sst[i];
+  for (int h = 0; h < P.n_hops; ++h) {
+    v->two_pi_nsamples[h] = P.hop[h].two_pi_nsamples;
+    v->ta_nres[h] = P.hop[h].ta_nres;
+    v->contig[h] = P.hop[h].contig;
+    for (int c = 0; c < CE_MAX_CDM; ++c) {
+      v->last_idx[h][c] = P.hop[h].last_idx[c];
+      for (int r = 0; r < 12; ++r) { v->r_ord[h][c][r] = P.hop[h].r_ord[c][r]; v->alpha[h][c][r] = P.hop[h].alpha[c][r]; }
+    }
+  }
+  delete p;
   return CE_OK;
 }
 

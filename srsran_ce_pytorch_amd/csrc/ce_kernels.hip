@@ -988,7 +988,16 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
     int64_t nxt = wg + gridDim.x;
     const float dep = rot_final[0].x;
     asm volatile("" : "+s"(nxt) : "v"(dep));
-    if (nxt < a.n_items) load_hop(item_of(nxt, a.n_ports, a.n_items), 0);
+    if (nxt < a.n_items) {
+      load_hop(item_of(nxt, a.n_ports, a.n_items), 0);
+    } else {
+      // last trip: give the registers a fresh (dead) value, otherwise the old pilots count as live across
+      // the TA stage just to reach the loop's back edge
+#pragma unroll
+      for (int i = 0; i < (REG ? KPT * ND : 1); ++i) xr[i] = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < (REG ? KPT * ND * L : 1); ++i) pr[i] = make_float2(0.f, 0.f);
+    }
   }
 #endif
   // ---------------------------------------------------------------- interpolate + replicate + CFO ramp (S10)

@@ -80,15 +80,14 @@ def _raise_for(code: int):
     raise RuntimeError(f"libce_hip: {msg} (code {code})")
 
 
-def make_plan(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_sym: int,
-              device: torch.device | str | int | None = None, interp: str = "linear") -> Plan:
-    """Resolve (hop1, hop2, config) into a cached GPU plan.
+def build_desc(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_sym: int, device_index: int = 0,
+               interp: str = "linear"):
+    """Validate like the reference and fill a ``ce_plan_desc``.  Returns ``(desc, key, keepalive)``; needs no GPU.
 
-    Raises what the reference raises for the same inputs: ``ValueError`` for an unknown
-    smoothing strategy (T:668) or a cyclic-prefix vector shorter than 14 (T:816),
-    ``AssertionError`` for overlapping hops / different DM-RS masks (T:862, T:869).
+    Raises what the reference raises for the same inputs: ``ValueError`` for an unknown smoothing strategy
+    (T:668) or a cyclic-prefix vector shorter than 14 (T:816), ``AssertionError`` for overlapping hops /
+    different DM-RS masks (T:862, T:869).
     """
-    lib = _lib.load()
     cfo_comp = bool(getattr(config, "CFOCompensate", True))
     smoothing = str(config.Smoothing) if getattr(config, "Smoothing", None) is not None else "filter"
     if smoothing not in _lib.SMOOTHING:
@@ -114,22 +113,13 @@ def make_plan(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_s
         assert r1.shape == r2.shape and bool(np.all(r1 == r2)), "The DM-RS mask should be the same for the two hops."
         hops.append((hop2, d2, r2, m2))
 
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if device.type != "cuda":
-        raise RuntimeError("the estimator runs on a ROCm GPU only (no CPU fallback)")
-    if device.index is None:
-        device = torch.device("cuda", torch.cuda.current_device())
-    key = (device.index, n_layers, n_prb_grid, n_sym, smoothing, cfo_comp, interp, scs, beta, alpha, cp14.tobytes(),
+    key = (device_index, n_layers, n_prb_grid, n_sym, smoothing, cfo_comp, interp, scs, beta, alpha, cp14.tobytes(),
            tuple((d.tobytes(), r.tobytes(), r.shape, m.tobytes(), int(h.PRBstart), int(h.nPRBs), int(h.startSymbol),
                   int(h.nAllocatedSymbols)) for h, d, r, m in hops))
-    plan = _PLAN_CACHE.get(key)
-    if plan is not None:
-        _PLAN_CACHE.move_to_end(key)
-        return plan
 
     desc = _lib.PlanDesc()
     desc.abi_version = _lib.CE_ABI_VERSION
-    desc.device = device.index
+    desc.device = device_index
     desc.n_prb_grid, desc.n_sym, desc.n_layers, desc.n_hops = n_prb_grid, n_sym, n_layers, len(hops)
     desc.smoothing, desc.cfo_compensate, desc.interp = _lib.SMOOTHING[smoothing], int(cfo_comp), _lib.INTERP[interp]
     desc.scs_hz, desc.beta_dmrs, desc.cnn_smoothing_alpha = scs, beta, alpha
@@ -153,10 +143,42 @@ def make_plan(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_s
         hd.mask_prbs = C.cast(buf, C.POINTER(C.c_uint8))
         hd.prb_start, hd.n_prbs = int(h.PRBstart), int(h.nPRBs)
         hd.start_symbol, hd.n_alloc_symbols = int(h.startSymbol), int(h.nAllocatedSymbols)
+    return desc, key, keep
 
+
+def derive_host(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_sym: int, interp: str = "linear"):
+    """Host-only view of what a plan would contain (``ce_plan_derive_host``): works without a GPU."""
+    lib = _lib.load()
+    desc, _, keep = build_desc(hop1, hop2, config, beta_dmrs, n_layers, n_prb_grid, n_sym, 0, interp)
+    view = _lib.PlanHostView()
+    rc = lib.ce_plan_derive_host(C.byref(desc), C.byref(view))
+    del keep
+    if rc != 0:
+        _raise_for(rc)
+    return view
+
+
+def make_plan(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_sym: int,
+              device: torch.device | str | int | None = None, interp: str = "linear") -> Plan:
+    """Resolve (hop1, hop2, config) into a cached GPU plan (exceptions: see ``build_desc``)."""
+    lib = _lib.load()
+    # validation first: the reference's error cases must surface even where no GPU is visible
+    desc, key, keep = build_desc(hop1, hop2, config, beta_dmrs, n_layers, n_prb_grid, n_sym, 0, interp)
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("the estimator runs on a ROCm GPU only (no CPU fallback)")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    desc.device = device.index
+    key = (device.index,) + key[1:]
+    plan = _PLAN_CACHE.get(key)
+    if plan is not None:
+        _PLAN_CACHE.move_to_end(key)
+        return plan
     handle = C.c_void_p()
     with torch.cuda.device(device):
         rc = lib.ce_plan_create(C.byref(desc), C.byref(handle))
+    del keep
     if rc != 0:
         _raise_for(rc)
     info = _lib.PlanInfo()

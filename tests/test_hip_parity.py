@@ -93,6 +93,22 @@ def test_hip_matches_oracle_random(case):
             check_outputs(ch[it], got, ref[0], rs, TOL_CH, TOL_SC, f"{case['name']}[{it}]/{layout}")
 
 
+def test_non_contiguous_prb_mask():
+    """The reference extracts pilots with maskPRBs but fills PRBstart..PRBstart+nPRBs:
+    a non-contiguous mask takes the table-lookup paths (pilot positions, TA scatter map)."""
+    case = S.case_spec("noncontig", 52, [S.hop_spec([2, 11], 4, 6)], seed=401, noise_var=0.05)
+    b = S.build_case(case, 2)
+    mp = np.zeros(52, bool)
+    mp[[4, 5, 6, 20, 21, 22]] = True
+    b.hop1.maskPRBs = mp
+    for layout in ("ref", "sym_major"):
+        ch, sc = _run_items(b, b.grids, layout)
+        for it in range(2):
+            ref = O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+            got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], sc[4][it]]
+            check_outputs(ch[it], got, ref[0], list(ref[1:]), TOL_CH, TOL_SC, f"noncontig[{it}]/{layout}")
+
+
 def test_multi_slot_per_slot_pilots():
     """[B=3 slots, R=2 ports] with a different pilot set per slot (pil_strides[0] != 0)."""
     dev = _dev()

@@ -76,3 +76,70 @@ def test_no_product_import_of_oracle():
         if f.suffix in {".py", ".hip", ".h", ".cpp"}:
             txt = f.read_text()
             assert "ce_oracle" not in txt and "oracle/" not in txt.replace("the oracle/", ""), f
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Host-side derivations of the C++ library (ce_plan_derive_host: no GPU) against the oracle / brute force
+# ------------------------------------------------------------------------------------------------------------
+import ce_oracle as O  # noqa: E402
+from conftest import golden_names  # noqa: E402
+from srsran_ce_pytorch_amd import synth as S  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_names("T"))
+def test_host_derivations_match_oracle(lib, name):
+    fx = load_fixture(name)
+    L = fx.pilots.shape[2]
+    v = E.derive_host(fx.hop1, fx.hop2, fx.config, fx.beta, L, fx.case["n_prb_grid"], fx.case["n_sym"])
+    hops = [fx.hop1] + ([fx.hop2] if len(fx.case["hops"]) > 1 else [])
+    assert v.n_re == fx.pilots.shape[0] and v.n_dmrs_total == fx.pilots.shape[1]
+    # symbol start times (T:809-820) and CFO sample span (T:418-426)
+    np.testing.assert_allclose(np.array(v.sst[:]), O.symbol_start_time(fx.config.CyclicPrefixDurations, fx.config.scs), rtol=1e-15)
+    for h, hop in enumerate(hops):
+        ix = np.flatnonzero(hop.DMRSsymbols)
+        if ix.size >= 2:
+            cpd = fx.config.CyclicPrefixDurations * (fx.config.scs / 1000.0)
+            n_samples = float(ix[1] - ix[0]) + float(np.sum(cpd[ix[0] + 1: ix[1] + 1]))
+            assert v.two_pi_nsamples[h] == pytest.approx(2 * np.pi * n_samples, rel=1e-15)
+    assert bool(v.cfo_estimated) == any(np.flatnonzero(h.DMRSsymbols).size >= 2 for h in hops)
+    # RC taps and virtual-pilot count (T:638-647, T:184-234)
+    if fx.config.Smoothing == "filter":
+        dpp = int(fx.hop1.DMRSREmask[:, 0].sum())
+        n_act = int(fx.hop1.maskPRBs.sum())
+        rc = O.get_rc_filter(12 // dpp, min(3, n_act))
+        assert v.rc_len == rc.size
+        np.testing.assert_allclose(np.array(v.rc[: rc.size]), rc, rtol=0, atol=2e-16)
+        assert v.n_pils == (min(12, rc.size // 2) if n_act > 1 else dpp)
+    # normalisers (T:901-915)
+    n_pilots = fx.hop1.nPRBs * int(fx.hop1.DMRSREmask[:, 0].sum()) * fx.pilots.shape[1]
+    assert v.n_pilots == n_pilots and v.noise_den == ((L + 1) // 2) * n_pilots - 1
+    # interpolation anchors / weights (T:311-338) against a brute-force searchsorted over the hop band
+    for h, hop in enumerate(hops):
+        for c in range((L + 1) // 2):
+            mask_all = np.tile(hop.DMRSREmask[:, c], hop.nPRBs)
+            filled = np.flatnonzero(mask_all)
+            dpp = int(hop.DMRSREmask[:, c].sum())
+            assert v.last_idx[h][c] == filled[-1]
+            for p in range(filled[0] + 1, filled[-1]):
+                ro = int(np.searchsorted(filled, p, side="left"))
+                q, r = divmod(p, 12)
+                assert q * dpp + v.r_ord[h][c][r] == ro
+                lp, rp = filled[ro - 1], filled[ro]
+                assert v.alpha[h][c][r] == np.float32(p - lp) / np.float32(rp - lp)
+
+
+def test_host_derivation_register_path_and_limits(lib):
+    h1, h2, cfg = S.numpy_hops(S.bench_case("filter"))
+    v = E.derive_host(h1, h2, cfg, 1.4125, 1, 273, 14)
+    assert v.reg_nd == 2 and v.filt_windowed == 1 and v.ta_nres[0] == 8 and v.contig[0] == 1
+    assert v.lds_bytes <= 53 * 1024            # three workgroups per CU
+    h1, h2, cfg = S.numpy_hops(S.case_spec("x", 52, [S.hop_spec([2, 7, 11], 4, 5, re_masks=[S.TYPE2_CDM0, S.TYPE2_CDM1])], n_layers=3))
+    v = E.derive_host(h1, h2, cfg, 1.0, 3, 52, 14)
+    assert v.reg_nd == 0 and v.ta_nres[0] == 16 and v.filt_windowed == 0
+    with pytest.raises(NotImplementedError):
+        h1, h2, cfg = S.numpy_hops(S.case_spec("too_wide", 400, [S.hop_spec([2, 11], 0, 400)]))
+        E.derive_host(h1, h2, cfg, 1.0, 1, 400, 14)
+    # non-contiguous maskPRBs (allowed by the reference: extraction uses maskPRBs, fill uses PRBstart/nPRBs)
+    h1, h2, cfg = S.numpy_hops(S.case_spec("nc", 52, [S.hop_spec([2, 11], 4, 6)]))
+    h1.maskPRBs = np.zeros(52, bool); h1.maskPRBs[[4, 5, 6, 20, 21, 22]] = True
+    assert E.derive_host(h1, h2, cfg, 1.0, 1, 52, 14).contig[0] == 0
