@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -290,14 +291,16 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       for (int c = 0; c < 5; ++c) P.cnn_rcp[c] = 1.0 / (0.25 * c + 1e-12);
     }
   }
-  // register path: every hop has the same 1 or 2 DM-RS symbols, one CDM group, band fits CE_KPT per thread
+  // register path: one layer (two layers' pilots would spill: measured slower than re-reading), every hop
+  // with the same 1 or 2 DM-RS symbols, band fits CE_KPT pilot REs per thread
   P.reg_nd = 0;
-  if (n_cdm == 1 && n_re <= CE_KPT * CE_THREADS) {
+  if (L == 1 && n_re <= CE_KPT * CE_THREADS) {
     const int nd = P.hop[0].n_dmrs;
     bool same = nd <= 2;
     for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
     if (same) P.reg_nd = nd;
   }
+  if (getenv("CE_FORCE_GENERIC")) P.reg_nd = 0;  // tuning knob: always take the re-read path
 
   const CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
   if (lay.total > 160 * 1024) { delete p; return fail(CE_ERR_UNSUPPORTED, "plan needs %d B of LDS (> 160 KiB)", lay.total); }

@@ -560,6 +560,10 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
     const float n_dmrs_f = (float)n_dmrs;
     const bool has_cfo = REG ? (ND >= 2) : (hp.has_cfo != 0);
     if (h > 0) load_hop(item, h);
+    if (NH > 1) {  // same reason as at the top of the item loop: keep each stage's thread-derived temporaries local
+      tid = tid0;
+      asm volatile("" : "+v"(tid) : : "memory");
+    }
 
     STAMP(1);
     // ------------------------------------------------------------ CFO of the hop (S4)
@@ -1233,7 +1237,7 @@ int prepare_t(int lds, int* blocks_per_cu) {
 
 }  // namespace
 
-// (layers, hops, register-path DM-RS count): ND in {1,2} only exists for one CDM group (L <= 2)
+// (layers, hops, register-path DM-RS count): ND in {1,2} only exists for one layer
 #define CE_DISPATCH(FN, ...)                                       \
   switch (n_layers * 100 + n_hops * 10 + reg_nd) {                 \
     case 110: return FN<1, 1, 0>(__VA_ARGS__);                     \
@@ -1243,11 +1247,7 @@ int prepare_t(int lds, int* blocks_per_cu) {
     case 121: return FN<1, 2, 1>(__VA_ARGS__);                     \
     case 122: return FN<1, 2, 2>(__VA_ARGS__);                     \
     case 210: return FN<2, 1, 0>(__VA_ARGS__);                     \
-    case 211: return FN<2, 1, 1>(__VA_ARGS__);                     \
-    case 212: return FN<2, 1, 2>(__VA_ARGS__);                     \
     case 220: return FN<2, 2, 0>(__VA_ARGS__);                     \
-    case 221: return FN<2, 2, 1>(__VA_ARGS__);                     \
-    case 222: return FN<2, 2, 2>(__VA_ARGS__);                     \
     case 310: return FN<3, 1, 0>(__VA_ARGS__);                     \
     case 320: return FN<3, 2, 0>(__VA_ARGS__);                     \
     case 410: return FN<4, 1, 0>(__VA_ARGS__);                     \

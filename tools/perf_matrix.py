@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): kernel time / achieved algorithmic GB/s over the geometries the kernel templates cover."""
+import sys, json
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
+import torch
+from srsran_ce_pytorch_amd import estimator as E, synth as S
+H, CS = S.hop_spec, S.case_spec
+BOTH = [S.TYPE1_CDM0, S.TYPE1_CDM1]
+cases = [
+    ("L1 2dmrs filter (register path)", S.bench_case("filter", 1), "linear"),
+    ("L1 2dmrs none", S.bench_case("none", 1), "linear"),
+    ("L1 2dmrs mean", S.bench_case("mean", 1), "linear"),
+    ("L2 2dmrs filter (register path)", S.bench_case("filter", 2), "linear"),
+    ("L4 2dmrs filter (generic path)", S.bench_case("filter", 4), "linear"),
+    ("L1 3dmrs filter (generic path)", CS("d3", 273, [H([2, 7, 11], 0, 273)]), "linear"),
+    ("L1 2 hops x 2dmrs", CS("h2", 273, [H([1, 5], 0, 136, 0, 7), H([8, 12], 137, 136, 7, 7)]), "linear"),
+    ("L1 type-2 mask filter", CS("t2", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "linear"),
+    ("L1 cnn in-painting", S.bench_case("filter", 1), "cnn"),
+    ("L1 cnn type-2 mask", CS("t2c", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "cnn"),
+    ("L1 25 PRB in 52", CS("small", 52, [H([2, 11], 10, 25)]), "linear"),
+]
+dev = torch.device("cuda:0")
+slots, ports = (int(sys.argv[1]) if len(sys.argv) > 1 else 2048), 4
+for name, case, interp in cases:
+    h1, h2, cfg = S.numpy_hops(case)
+    L = case["n_layers"]
+    plan = E.make_plan(h1, h2, cfg, case["beta"], L, case["n_prb_grid"], 14, dev, interp)
+    rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
+    out = E.estimate_with_plan(plan, rx, pil)
+    torch.cuda.synchronize()
+    ms = min(E.time_with_plan(plan, rx, pil, out, 1, 5) for _ in range(2))
+    b = slots * (ports * plan.alg_bytes_per_item + plan.pilot_bytes_per_slot)
+    print(f"{name:36s} {ms:8.3f} ms  {b / ms / 1e6:7.0f} GB/s  {slots / ms * 1e3 / 1e6:6.2f} M slots/s  lds={plan.lds_bytes}", flush=True)
+    del rx, pil, out
