@@ -222,6 +222,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       double cp_sum = 0.0;
       for (int s = i0 + 1; s <= i1 && s < CE_MAX_SYMBOLS; ++s) cp_sum += d->cp_ms[s] * (d->scs_hz / 1000.0);
       H.two_pi_nsamples = 2.0 * M_PI * ((double)(i1 - i0) + cp_sum);
+      H.inv_two_pi_nsamples = 1.0 / H.two_pi_nsamples;
     }
   }
   P.n_re = n_re; P.n_re_pad = (n_re + 1) & ~1;
@@ -235,6 +236,8 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   const double n_pilots = (double)(d->hop[0].n_prbs * P.hop[0].dpp[0] * n_dmrs_total);
   P.n_pilots = n_pilots;
   P.noise_den = (double)n_cdm * n_pilots - 1.0;
+  P.inv_n_pilots = 1.0 / n_pilots; P.inv_layers = 1.0 / (double)L; P.inv_noise_den = 1.0 / P.noise_den;
+  P.inv_denom_cdm = 1.0 / (double)n_cdm; P.inv_scs = 1.0 / d->scs_hz;
 
   if (d->smoothing == CE_SMOOTH_FILTER) {
     const int dpp0 = P.hop[0].dpp[0];

@@ -618,7 +618,7 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
         for (int l = 0; l + 1 < L; l += 2)  // CDM pairs are summed before the angle (T:410-413)
           ang += (double)atan2f((float)(acc[2 * l + 1] + acc[2 * l + 3]), (float)(acc[2 * l] + acc[2 * l + 2]));
         if (L & 1) ang += (double)atan2f((float)acc[2 * L - 1], (float)acc[2 * L - 2]);
-        cfo_hop = ang / hp.two_pi_nsamples / plan->denom_cdm;
+        cfo_hop = ang * hp.inv_two_pi_nsamples * plan->inv_denom_cdm;  // T:426, reciprocals from the plan (<= 1 ulp)
         if (tid == 0) misc[h] = cfo_hop;
       }
     }
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
       offer(b1, pw1);
       kh = wave_max_u64(kh);
       kt = wave_max_u64(kt);
-      unsigned long long* ared = reinterpret_cast<unsigned long long*>(red);
+      unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 48);  // own slot: no barrier needed after use
       if ((tid & 63) == 0) {
         ared[(tid >> 6) * 2] = kh;
         ared[(tid >> 6) * 2 + 1] = kt;
@@ -947,9 +947,8 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
         const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
         const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
         const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
-        tot_ta += (double)i_max / (double)CE_FFT_SIZE / plan->scs;
+        tot_ta += (double)i_max * (1.0 / (double)CE_FFT_SIZE) * plan->inv_scs;  // T:698
       }
-      __syncthreads();
     }
   }
 
@@ -973,11 +972,11 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
     }
     rot_final[tid] = r;
     if (tid == 0) {
-      const double np = plan->n_pilots;
-      a.rsrp[item] = tot_rsrp / np / (double)L;
-      a.epre[item] = tot_epre / np;
-      a.noise[item] = tot_noise / plan->noise_den;
-      a.ta[item] = (NH == 2) ? tot_ta / 2.0 : tot_ta;
+      const double np = plan->inv_n_pilots;
+      a.rsrp[item] = tot_rsrp * np * plan->inv_layers;
+      a.epre[item] = tot_epre * np;
+      a.noise[item] = tot_noise * plan->inv_noise_den;
+      a.ta[item] = (NH == 2) ? tot_ta * 0.5 : tot_ta;
       a.cfo[item] = plan->cfo_estimated ? cfo * plan->scs : __longlong_as_double(0x7FF8000000000000ll);
     }
   }

@@ -29,6 +29,7 @@ struct CeDevHop {
   int32_t r_ord[CE_MAX_CDM][12];      // right-anchor ordinal inside the PRB for RE r (T:325)
   float alpha[CE_MAX_CDM][12];        // (pos-left)/(right-left) in float32 (T:333-337)
   double two_pi_nsamples;             // 2*pi*nSamples (T:418-426)
+  double inv_two_pi_nsamples;
   int32_t ta_nres;                    // residues mod 16 of the subcarriers the TA scatter touches (T:672-675)
   int32_t ta_res[16];
   int32_t ta_inv_off;                 // offset of this hop's subcarrier -> pilot-ordinal table (0xFFFF = no pilot)
@@ -49,6 +50,7 @@ struct CeDevPlan {
   int32_t scratch_bytes, wr_ch_log2;  // LDS scratch size; log2 of the writer's subcarrier chunk
   float beta_f;
   double beta, scs, denom_cdm, n_pilots, noise_den;
+  double inv_n_pilots, inv_layers, inv_noise_den, inv_denom_cdm, inv_scs;  // reciprocals: one multiply instead of a float64 divide
   double sst[CE_MAX_SYMBOLS];         // symbolStartTime (T:809-820)
   double sst_dmrs[CE_MAX_HOPS][CE_MAX_SYMBOLS];  // symbolStartTime at each hop's DM-RS symbols
   double rc[CE_MAX_RC_TAPS];          // RC taps, unit sum (T:184-234)
@@ -89,7 +91,7 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
   l.off_red = o;      o += (CE_THREADS / 64) * 16 * 8;           // 16 doubles per wave
   l.off_rot = o;      o += (1 + 2 * CE_MAX_HOPS) * 16 * 8;       // final, per-hop -/+ phasors, 16 float2 each
   l.off_tab = o;      o += CE_MAX_HOPS * CE_MAX_CDM * 12 * 8;    // {alpha, r_ord} pairs
-  l.off_misc = o;     o += 48 * 8;                               // doubles: cfo_hop[2], pad[2], sst[16], sst_dmrs[2][14]
+  l.off_misc = o;     o += 56 * 8;                               // doubles: cfo_hop[2], pad[2], sst[16], sst_dmrs[2][14], TA arg-max keys[8]
   l.off_tw = o;       o += (256 + 16) * 8;                       // W256^j, W4096^i for the TA transform
   l.off_rcz = o;      o += ((CE_RCZ_LEN + 1) & ~1) * 8;          // zero-padded RC taps (float64)
   l.total = (o + 15) & ~15;
