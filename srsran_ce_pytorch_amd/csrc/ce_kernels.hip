@@ -41,6 +41,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_NT_STORE
 #define CE_NT_STORE 0
 #endif
+#ifndef CE_PRIO
+#define CE_PRIO 0         // 1: estimation stages at raised wave priority, writer at 0; 2: writer raised
+#endif
 
 #if defined(CE_STAMPS)
 // diagnostic build only (tools/stamps.py): per-stage wall-clock stamps of thread 0, written to a buffer
@@ -551,6 +554,9 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
   const float2* pil = a.pil + slot * a.ps_b;
   double tot_epre = 0.0, tot_noise = 0.0, tot_rsrp = 0.0, tot_ta = 0.0;
   STAMP(0);
+#if CE_PRIO == 1
+  __builtin_amdgcn_s_setprio(2);
+#endif
 
 #pragma unroll 1
   for (int h = 0; h < NH; ++h) {
@@ -983,6 +989,11 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
   __syncthreads();
 
   STAMP(8);
+#if CE_PRIO == 1
+  __builtin_amdgcn_s_setprio(0);
+#elif CE_PRIO == 2
+  __builtin_amdgcn_s_setprio(3);  // writer waves first: keep the store stream fed
+#endif
 #if CE_PERSIST
   {
     // Prefetch the next item's pilots; they are consumed at the top of the next trip.  The index is tied
