@@ -35,15 +35,6 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_PERSIST
 #define CE_PERSIST 0      // 1: persistent workgroups that prefetch the next item's pilots before writing
 #endif
-#ifndef CE_STORE_WINDOW
-#define CE_STORE_WINDOW 0 // >0: a wave keeps at most this many grid stores in flight (s_waitcnt vmcnt)
-#endif
-#ifndef CE_NT_STORE
-#define CE_NT_STORE 0
-#endif
-#ifndef CE_PRIO
-#define CE_PRIO 0         // 1: estimation stages at raised wave priority, writer at 0; 2: writer raised
-#endif
 
 #if defined(CE_STAMPS)
 // diagnostic build only (tools/stamps.py): per-stage wall-clock stamps of thread 0, written to a buffer
@@ -71,20 +62,10 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define CE_STR2(x) #x
-#define CE_STR(x) CE_STR2(x)
-__device__ __forceinline__ void store_f4(float4* p, float4 v) {
-#if CE_NT_STORE
-  __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
-#else
-  *p = v;
-#endif
-#if CE_STORE_WINDOW > 0
-  // flow control: a deep per-CU store queue is what other workgroups' pilot loads wait behind
-  asm volatile("s_waitcnt vmcnt(" CE_STR(CE_STORE_WINDOW) ")" ::: "memory");
-#endif
-}
+// Measured and dropped (tools/ablate.py, same-box A/B): non-temporal stores, a per-wave cap on stores in
+// flight (s_waitcnt vmcnt(N) after each store, N = 2..16), raised/lowered wave priority around the writer,
+// touching a later work item's DM-RS rows ahead of time -- none faster, the last one 17 % slower.
+__device__ __forceinline__ void store_f4(float4* p, float4 v) { *p = v; }
 
 // Compiler fence on a register value (no instruction).  Used after the CFO stage so its 14 pilot
 // products are not kept alive (56 VGPRs) for re-use by the LS stage across two barriers.
@@ -554,9 +535,6 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
   const float2* pil = a.pil + slot * a.ps_b;
   double tot_epre = 0.0, tot_noise = 0.0, tot_rsrp = 0.0, tot_ta = 0.0;
   STAMP(0);
-#if CE_PRIO == 1
-  __builtin_amdgcn_s_setprio(2);
-#endif
 
 #pragma unroll 1
   for (int h = 0; h < NH; ++h) {
@@ -989,11 +967,6 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
   __syncthreads();
 
   STAMP(8);
-#if CE_PRIO == 1
-  __builtin_amdgcn_s_setprio(0);
-#elif CE_PRIO == 2
-  __builtin_amdgcn_s_setprio(3);  // writer waves first: keep the store stream fed
-#endif
 #if CE_PERSIST
   {
     // Prefetch the next item's pilots; they are consumed at the top of the next trip.  The index is tied
