@@ -405,6 +405,7 @@ static int check_batch(const ce_plan* plan, const void* rx, const int64_t* rs, c
   a->pil = (const float2*)pilots; a->ps_b = ps[0]; a->ps_re = ps[1]; a->ps_sym = ps[2]; a->ps_l = ps[3];
   a->out = (float2*)ch_est; a->noise = noise; a->rsrp = rsrp; a->epre = epre; a->ta = ta; a->cfo = cfo;
   a->n_items = n_slots * n_ports; a->n_ports = n_ports;
+  a->item0 = 0; a->n_local = a->n_items;
   return CE_OK;
 }
 

@@ -32,6 +32,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_MIN_WAVES
 #define CE_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for (3 workgroups per CU; 4 would spill)
 #endif
+#ifndef CE_RELOAD_RESID
+#define CE_RELOAD_RESID 0 // 1: the residual stage re-reads rx / pilots instead of keeping them in registers across smoothing
+#endif
 #ifndef CE_PERSIST
 #define CE_PERSIST 0      // 1: persistent workgroups that prefetch the next item's pilots before writing
 #endif
@@ -418,6 +421,72 @@ __device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils
   __syncthreads();
 }
 
+// Grid writer, direct form (L = 1, 3; 14 symbols): each of 252 threads owns ONE (symbol, layer) float4 phase of
+// the 7L float4 a subcarrier spans, so its two CFO phasors and hop/layer selection are thread constants and a
+// workgroup iteration stores 4032 contiguous bytes.  Its subcarriers advance by whole PRBs, so its RE position
+// inside the PRB -- hence its interpolation weight and anchor ordinals (T:325-337) -- is constant too:
+// interpolate straight from P in LDS (left + alpha (right - left), also AT pilots, as the reference does), no
+// staging buffer, no barrier.
+template <int L, int NH>
+__device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ plan, const float2* P, const float2* tab,
+                                                  const float2* rot_final, float4* out4, int n_re, int n_re_pad, int tid) {
+  constexpr int ROW4 = 7 * L, ACTIVE = (NT / 252) * 252, SC_STEP = ACTIVE / ROW4, QS = SC_STEP / 12;
+  static_assert(SC_STEP % 12 == 0, "direct form needs whole-PRB steps");
+  const int ph = tid % ROW4, sc_lane = tid / ROW4, r12 = sc_lane % 12;
+  float2 rsel[2];
+  const float2* Pe[2];
+  float al[2];
+  int ro[2], q[2], nprb[2], dro[2];
+  bool tail_r[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int rem = 2 * ph + e, sym = rem / L, l = rem - sym * L;
+    int h = -1;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh)
+      if (sym >= plan->hop[hh].sym0 && sym < plan->hop[hh].sym1) h = hh;  // a later hop overwrites (T:872-896)
+    rsel[e] = h < 0 ? make_float2(0.f, 0.f) : rot_final[sym];            // rot_final == 1 when no CFO ramp applies
+    h = h < 0 ? 0 : h;
+    const CeDevHop& hp = plan->hop[h];
+    const int c = l >> 1;
+    const float2 t = tab[(h * CE_MAX_CDM + c) * 12 + r12];
+    al[e] = t.x;
+    Pe[e] = P + (h * L + l) * n_re_pad;
+    q[e] = sc_lane / 12 - hp.prb_start;
+    nprb[e] = hp.n_prbs;
+    dro[e] = QS * hp.dpp[c];
+    ro[e] = q[e] * hp.dpp[c] + __float_as_int(t.y);
+    tail_r[e] = 12 * (hp.n_prbs - 1) + r12 >= hp.last_idx[c];
+  }
+  if (tid < ACTIVE) {
+    float4* o = out4 + tid;
+    const int n_iter = (plan->n_sc - sc_lane + SC_STEP - 1) / SC_STEP;
+#pragma unroll 2
+    for (int it = 0; it < n_iter; ++it) {
+      float2 y[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (e == 1 && L == 1 && NH == 1) {  // same subcarrier, same layer, same hop: reuse the interpolation
+          y[1] = y[0];
+        } else {
+          const bool valid = (unsigned)q[e] < (unsigned)nprb[e];
+          int hi = ro[e], lo = ro[e] - 1;
+          if (q[e] == nprb[e] - 1 && tail_r[e]) lo = hi = n_re - 1;  // at/after the last pilot: hold (T:316,321)
+          lo = lo < 0 ? 0 : lo;                                       // at/before the first pilot: hold (T:315,320)
+          if (!valid) lo = hi = 0;
+          const float2 u = Pe[e][lo], v = Pe[e][hi];
+          y[e] = valid ? make_float2(u.x + al[e] * (v.x - u.x), u.y + al[e] * (v.y - u.y)) : make_float2(0.f, 0.f);
+          q[e] += QS;
+          ro[e] += dro[e];
+        }
+      }
+      const float2 ya = cmul(y[0], rsel[0]), yb = cmul(y[1], rsel[1]);
+      store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
+      o += ACTIVE;
+    }
+  }
+}
+
 // L layers, NH hops; ND = DM-RS symbols per hop whose pilot REs (and pilots) stay in registers between the CFO,
 // LS and residual stages (needs one CDM group and n_re <= KPT*NT); ND = 0 re-reads them from global memory
 // (L2) in each of the three stages and works for any geometry.
@@ -447,6 +516,11 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
   float2* tw256 = reinterpret_cast<float2*>(smem + lay.off_tw);          // [256] W256^j = exp(+j 2 pi j / 256)
   float2* tw16 = tw256 + 256;                                            // [16]  W4096^i
   double* rcz = reinterpret_cast<double*>(smem + lay.off_rcz);           // zero-padded RC taps
+  // LDS copy of the plan: every stage after the first barrier reads its parameters from here.  Scalar loads from
+  // global memory queue behind the chip-wide store stream (microseconds each under load); LDS reads do not.
+  const CeDevPlan* lp = reinterpret_cast<const CeDevPlan*>(smem + lay.off_plan);
+  for (int i = tid; i < (int)(sizeof(CeDevPlan) / 4); i += NT)
+    reinterpret_cast<uint32_t*>(smem + lay.off_plan)[i] = reinterpret_cast<const uint32_t*>(plan)[i];
 
   const float beta_f = plan->beta_f;
   const bool cfo_comp = plan->cfo_comp != 0;
@@ -509,17 +583,17 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
       }
     }
   };
-  if (blockIdx.x < a.n_items) load_hop(item_of(blockIdx.x, a.n_ports, a.n_items), 0);
+  if (blockIdx.x < a.n_local) load_hop(a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local), 0);
 
 #if CE_PERSIST
   // persistent workgroups: items blockIdx.x, blockIdx.x + gridDim.x, ...
 #pragma unroll 1
-  for (int64_t wg = blockIdx.x; wg < a.n_items; wg += gridDim.x) {
-  const int64_t item = item_of(wg, a.n_ports, a.n_items);
+  for (int64_t wg = blockIdx.x; wg < a.n_local; wg += gridDim.x) {
+  const int64_t item = a.item0 + item_of(wg, a.n_ports, a.n_local);
 #else
   {
-  if (blockIdx.x >= a.n_items) return;
-  const int64_t item = item_of(blockIdx.x, a.n_ports, a.n_items);
+  if (blockIdx.x >= a.n_local) return;
+  const int64_t item = a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local);
 #endif
   // Everything a stage derives from the thread index and the plan is loop-invariant; left alone, the
   // compiler hoists all of it out of the item loop and keeps ~100 extra registers live across every
@@ -538,7 +612,8 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
 
 #pragma unroll 1
   for (int h = 0; h < NH; ++h) {
-    const CeDevHop& hp = plan->hop[h];
+    const CeDevHop& hp = plan->hop[h];  // global copy: load + CFO stages (before the first barrier)
+    const CeDevHop& lh = lp->hop[h];    // LDS copy: everything after
     float2* Ph = P + h * L * n_re_pad;
     const int n_dmrs = REG ? ND : hp.n_dmrs;
     const float n_dmrs_f = (float)n_dmrs;
@@ -655,10 +730,10 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
           const int64_t sc = pilot_sc(hp, re_idx, c, k);
           float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
           for (int s = 0; s < n_dmrs; ++s) {
-            const float2 x = rx[sc * a.rs_sc + hp.dmrs_sym[s] * a.rs_sym];
+            const float2 x = rx[sc * a.rs_sc + lh.dmrs_sym[s] * a.rs_sym];
             epre_part += x.x * x.x + x.y * x.y;
             const float2 rn = rot_neg[s];
-            const int64_t pb = k * a.ps_re + (hp.pil_sym0 + s) * a.ps_sym;
+            const int64_t pb = k * a.ps_re + (lh.pil_sym0 + s) * a.ps_sym;
             acc0 = cadd(acc0, cmul(cmul_conj(x, pil[pb + (2 * c) * a.ps_l]), rn));
             if (2 * c + 1 < L) acc1 = cadd(acc1, cmul(cmul_conj(x, pil[pb + (2 * c + 1) * a.ps_l]), rn));
           }
@@ -687,7 +762,7 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
     STAMP(4);
     // ------------------------------------------------------------ frequency smoothing (S7)
     if (CE_ABLATE & 2) {
-    } else if (plan->smoothing == CE_SMOOTH_MEAN) {
+    } else if (lp->smoothing == CE_SMOOTH_MEAN) {
       double m[2 * L];
 #pragma unroll
       for (int i = 0; i < 2 * L; ++i) m[i] = 0.0;
@@ -706,11 +781,11 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
           Ph[l * n_re_pad + k] = make_float2((float)(m[2 * l] / (double)n_re), (float)(m[2 * l + 1] / (double)n_re));
       }
       __syncthreads();
-    } else if (plan->smoothing == CE_SMOOTH_FILTER) {
-      const int n_pils = plan->n_pils, rc_len = plan->rc_len;
+    } else if (lp->smoothing == CE_SMOOTH_FILTER) {
+      const int n_pils = lp->n_pils, rc_len = lp->rc_len;
       const int pad = rc_len / 2;
-      const double vmx = plan->vp_mx, vin = plan->vp_inv_n, vid = plan->vp_inv_denom;
-      if (plan->filt_windowed) {  // host sets it only for the 15-tap filter; other lengths take the generic form
+      const double vmx = lp->vp_mx, vin = lp->vp_inv_n, vid = lp->vp_inv_denom;
+      if (lp->filt_windowed) {  // host sets it only for the 15-tap filter; other lengths take the generic form
         float2* vpb = scratch;  // [2][16]: virtual pilot at distance e+1 beyond the head / tail edge
 #pragma unroll 1
         for (int l = 0; l < L; ++l) {
@@ -719,7 +794,7 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
         }
       } else {
         // generic form (very wide bands): copy [virtual ; P ; virtual] to the scratch, one output per thread
-        const int ext_len = plan->ext_len, lpp = plan->filt_lpp;
+        const int ext_len = lp->ext_len, lpp = lp->filt_lpp;
 #pragma unroll 1
         for (int l0 = 0; l0 < L; l0 += lpp) {
           const int nl = min(lpp, L - l0);
@@ -753,9 +828,9 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
           __syncthreads();
         }
       }
-      if (plan->interp == CE_INTERP_CNN && plan->cnn_alpha > 0.f) {
+      if (lp->interp == CE_INTERP_CNN && lp->cnn_alpha > 0.f) {
         // optional blend with one low-pass pass over the smoothed pilots (src/ce_dl_cnn.py:712-715)
-        const float al = plan->cnn_alpha;
+        const float al = lp->cnn_alpha;
 #pragma unroll 1
         for (int l = 0; l < L; ++l) {
           float2* Pl = Ph + l * n_re_pad;
@@ -780,7 +855,7 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
     // ------------------------------------------------------------ residual noise, RSRP (S9, S11)
     {
       float noise_part = 0.f, rsrp_part = 0.f;
-      if constexpr (REG) {
+      if constexpr (REG && !CE_RELOAD_RESID) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
           const int k = tid + i * NT;
@@ -815,9 +890,9 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
             const float2 h0 = Ph[(2 * c) * n_re_pad + k];
             const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * n_re_pad + k] : make_float2(0.f, 0.f);
             for (int s = 0; s < n_dmrs; ++s) {
-              const float2 x = rx[sc * a.rs_sc + hp.dmrs_sym[s] * a.rs_sym];
+              const float2 x = rx[sc * a.rs_sc + lh.dmrs_sym[s] * a.rs_sym];
               const float2 rp = rot_pos[s];
-              const int64_t pb = k * a.ps_re + (hp.pil_sym0 + s) * a.ps_sym;
+              const int64_t pb = k * a.ps_re + (lh.pil_sym0 + s) * a.ps_sym;
               float2 est = cmul(pil[pb + (2 * c) * a.ps_l], cmul(h0, rp));
               if (2 * c + 1 < L) est = cadd(est, cmul(pil[pb + (2 * c + 1) * a.ps_l], cmul(h1, rp)));
               const float dr = x.x - beta_f * est.x, di = x.y - beta_f * est.y;
@@ -830,7 +905,7 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
       block_sum<3>(v, red);
       tot_epre += v[0];
       tot_noise += v[1];
-      tot_rsrp += plan->beta * plan->beta * v[2] * (double)n_dmrs;
+      tot_rsrp += lp->beta * lp->beta * v[2] * (double)n_dmrs;
     }
 
     STAMP(6);
@@ -843,10 +918,10 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
       float pw0 = 0.f, pw1 = 0.f;  // bins tid and tid + NT of the 288 examined (b < 144: delay side, else advance side)
       const int b0 = tid, b1 = tid + NT;
       constexpr int NB = 2 * CE_TA_HALF;
-      const int nres = hp.ta_nres;
-      const uint16_t* inv = ta_inv + hp.ta_inv_off;
+      const int nres = lh.ta_nres;
+      const uint16_t* inv = ta_inv + lh.ta_inv_off;
       const int ri = tid >> 4, a4 = tid & 15;
-      const unsigned long long res_packed = hp.ta_res_packed;
+      const unsigned long long res_packed = lh.ta_res_packed;
       auto bin_power = [&](int k) -> float {
         const int q = k & 255, off = (q & 15) * 17 + (q >> 4);
         float2 acc = make_float2(0.f, 0.f);
@@ -857,8 +932,8 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
         return acc.x * acc.x + acc.y * acc.y;
       };
       // subcarrier n -> ordinal of the pilot it carries (last CDM group), or -1
-      const int contig = hp.contig, dpp_last = hp.dpp[NC - 1], prb0 = hp.prb_start, nprb = hp.n_prbs;
-      const unsigned long long ord_packed = hp.ord_packed;
+      const int contig = lh.contig, dpp_last = lh.dpp[NC - 1], prb0 = lh.prb_start, nprb = lh.n_prbs;
+      const unsigned long long ord_packed = lh.ord_packed;
       auto pilot_at = [&](int n) -> int {
         if (contig) {
           const int q = n / 12, rem = n - 12 * q, pq = q - prb0;
@@ -931,20 +1006,20 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
         const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
         const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
         const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
-        tot_ta += (double)i_max * (1.0 / (double)CE_FFT_SIZE) * plan->inv_scs;  // T:698
+        tot_ta += (double)i_max * (1.0 / (double)CE_FFT_SIZE) * lp->inv_scs;  // T:698
       }
     }
   }
 
   STAMP(7);
   // ---------------------------------------------------------------- slot-level epilogue (T:898-937)
-  const bool apply_rot = cfo_comp && plan->cfo_estimated && !(CE_ABLATE & 16);
+  const bool apply_rot = cfo_comp && lp->cfo_estimated && !(CE_ABLATE & 16);
   if (tid < 16) {
     double cfo = 0.0;  // running mean over the hops that estimated one (T:605-609)
     bool have = false;
 #pragma unroll
     for (int h = 0; h < NH; ++h)
-      if (plan->hop[h].has_cfo && !(CE_ABLATE & 16)) {
+      if (lp->hop[h].has_cfo && !(CE_ABLATE & 16)) {
         cfo = have ? (cfo + misc[h]) / 2 : misc[h];
         have = true;
       }
@@ -956,12 +1031,12 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
     }
     rot_final[tid] = r;
     if (tid == 0) {
-      const double np = plan->inv_n_pilots;
-      a.rsrp[item] = tot_rsrp * np * plan->inv_layers;
+      const double np = lp->inv_n_pilots;
+      a.rsrp[item] = tot_rsrp * np * lp->inv_layers;
       a.epre[item] = tot_epre * np;
-      a.noise[item] = tot_noise * plan->inv_noise_den;
+      a.noise[item] = tot_noise * lp->inv_noise_den;
       a.ta[item] = (NH == 2) ? tot_ta * 0.5 : tot_ta;
-      a.cfo[item] = plan->cfo_estimated ? cfo * plan->scs : __longlong_as_double(0x7FF8000000000000ll);
+      a.cfo[item] = lp->cfo_estimated ? cfo * lp->scs : __longlong_as_double(0x7FF8000000000000ll);
     }
   }
   __syncthreads();
@@ -975,8 +1050,8 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
     int64_t nxt = wg + gridDim.x;
     const float dep = rot_final[0].x;
     asm volatile("" : "+s"(nxt) : "v"(dep));
-    if (nxt < a.n_items) {
-      load_hop(item_of(nxt, a.n_ports, a.n_items), 0);
+    if (nxt < a.n_local) {
+      load_hop(a.item0 + item_of(nxt, a.n_ports, a.n_local), 0);
     } else {
       // last trip: give the registers a fresh (dead) value, otherwise the old pilots count as live across
       // the TA stage just to reach the loop's back edge
@@ -988,21 +1063,21 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
   }
 #endif
   // ---------------------------------------------------------------- interpolate + replicate + CFO ramp (S10)
-  const int n_sym = plan->n_sym;
+  const int n_sym = lp->n_sym;
   const int row = n_sym * L;  // complex values per subcarrier
-  const int64_t total = (int64_t)plan->n_sc * row;
+  const int64_t total = (int64_t)lp->n_sc * row;
   float2* out = a.out + item * total;
 
   // linear interpolation at hop-relative subcarrier p of layer l (T:311-338); exact pilot value outside
   // the first/last pilot, left + alpha*(right-left) elsewhere (also AT pilots, as the reference does)
   auto interp_at = [&](int h, int l, int p) -> float2 {
-    const CeDevHop& hp = plan->hop[h];
+    const CeDevHop& lh = lp->hop[h];
     const int c = l >> 1;
     const int q = p / 12, r = p - 12 * q;
     const float2 t = tab[(h * CE_MAX_CDM + c) * 12 + r];
-    int ro = q * hp.dpp[c] + __float_as_int(t.y);
+    int ro = q * lh.dpp[c] + __float_as_int(t.y);
     int lo = ro - 1;
-    if (p >= hp.last_idx[c]) lo = ro = n_re - 1;
+    if (p >= lh.last_idx[c]) lo = ro = n_re - 1;
     lo = lo < 0 ? 0 : lo;
     const float2* Pl = P + (h * L + l) * n_re_pad;
     const float2 u = Pl[lo], v = Pl[ro];
@@ -1019,7 +1094,7 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
     constexpr int ROW4 = 7 * L;             // float4 per subcarrier
     constexpr int ACTIVE = (NT / 252) * 252;
     constexpr int SC_STEP = ACTIVE / ROW4;  // subcarriers per workgroup iteration
-    const int ch_log2 = plan->wr_ch_log2, CH = 1 << ch_log2;
+    const int ch_log2 = lp->wr_ch_log2, CH = 1 << ch_log2;
     const int ph = tid % ROW4, sc_lane = tid / ROW4;
     int hsel[2], lsel[2];
     float2 rsel[2];
@@ -1030,29 +1105,29 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
       int h = -1;
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh)
-        if (sym >= plan->hop[hh].sym0 && sym < plan->hop[hh].sym1) h = hh;  // a later hop overwrites (T:872-896)
+        if (sym >= lp->hop[hh].sym0 && sym < lp->hop[hh].sym1) h = hh;  // a later hop overwrites (T:872-896)
       hsel[e] = h < 0 ? 0 : h;
       rsel[e] = h < 0 ? make_float2(0.f, 0.f) : rot_final[sym];  // rot_final == 1 when no CFO ramp applies
     }
     float4* out4 = reinterpret_cast<float4*>(out);
-    if (plan->interp == CE_INTERP_CNN) {
+    if (lp->interp == CE_INTERP_CNN) {
       // in-painted response for every (hop, layer), whole band at once, then the same phase-owning store loop
-      const int hs = plan->cnn_h_stride, n_sc = plan->n_sc;
-      float2* pong = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(scratch) + plan->cnn_pong_off);
-      unsigned char* m_a = reinterpret_cast<unsigned char*>(scratch) + plan->cnn_m_off;
-      unsigned char* m_b = m_a + ((plan->cnn_n_max + 15) & ~15);
+      const int hs = lp->cnn_h_stride, n_sc = lp->n_sc;
+      float2* pong = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(scratch) + lp->cnn_pong_off);
+      unsigned char* m_a = reinterpret_cast<unsigned char*>(scratch) + lp->cnn_m_off;
+      unsigned char* m_b = m_a + ((lp->cnn_n_max + 15) & ~15);
 #pragma unroll 1
       for (int hl = 0; hl < NH * L; ++hl) {
         const int h = hl / L, l = hl - h * L;
-        const CeDevHop& hp = plan->hop[h];
+        const CeDevHop& lh = lp->hop[h];
         float2* row = scratch + hl * hs;
         for (int i = tid; i < n_sc; i += NT)
-          if (i < hp.sc0 || i >= hp.sc0 + hp.n_sc_hop) row[i] = make_float2(0.f, 0.f);
+          if (i < lh.sc0 || i >= lh.sc0 + lh.n_sc_hop) row[i] = make_float2(0.f, 0.f);
         const int c = l >> 1;
-        const unsigned mask12 = (unsigned)((hp.mask12 >> (16 * c)) & 0xFFFu);
-        const int n_it = hp.n_sc_hop / 8 > 6 ? hp.n_sc_hop / 8 : 6;  // C:293
-        cnn_inpaint_layer(row + hp.sc0, pong, m_a, m_b, P + (h * L + l) * n_re_pad, hp.n_sc_hop, mask12, hp.dpp[c], n_it,
-                          plan->cnn_rcp, tid);
+        const unsigned mask12 = (unsigned)((lh.mask12 >> (16 * c)) & 0xFFFu);
+        const int n_it = lh.n_sc_hop / 8 > 6 ? lh.n_sc_hop / 8 : 6;  // C:293
+        cnn_inpaint_layer(row + lh.sc0, pong, m_a, m_b, P + (h * L + l) * n_re_pad, lh.n_sc_hop, mask12, lh.dpp[c], n_it,
+                          lp->cnn_rcp, tid);
       }
       __syncthreads();
       const float2* HA = scratch + (hsel[0] * L + lsel[0]) * hs;
@@ -1067,68 +1142,20 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
         }
       }
     } else if constexpr (SC_STEP % 12 == 0) {
-      // Direct form (L = 1, 3): a thread's subcarriers advance by whole PRBs, so its RE position inside the
-      // PRB -- hence its interpolation weight and anchor ordinals (T:325-337) -- is constant: interpolate
-      // straight from P in LDS, no staging buffer, no barrier.
-      constexpr int QS = SC_STEP / 12;
-      const int r12 = sc_lane % 12;
-      const float2* Pe[2];
-      float al[2];
-      int ro[2], q[2], nprb[2], dro[2];
-      bool tail_r[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const CeDevHop& hp = plan->hop[hsel[e]];
-        const int c = lsel[e] >> 1;
-        const float2 t = tab[(hsel[e] * CE_MAX_CDM + c) * 12 + r12];
-        al[e] = t.x;
-        Pe[e] = P + (hsel[e] * L + lsel[e]) * n_re_pad;
-        q[e] = sc_lane / 12 - hp.prb_start;
-        nprb[e] = hp.n_prbs;
-        dro[e] = QS * hp.dpp[c];
-        ro[e] = q[e] * hp.dpp[c] + __float_as_int(t.y);
-        tail_r[e] = 12 * (hp.n_prbs - 1) + r12 >= hp.last_idx[c];
-      }
-      if (tid < ACTIVE) {
-        float4* o = out4 + tid;
-        const int n_iter = (plan->n_sc - sc_lane + SC_STEP - 1) / SC_STEP;
-#pragma unroll 2
-        for (int it = 0; it < n_iter; ++it) {
-          float2 y[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            if (e == 1 && L == 1 && NH == 1) {  // same subcarrier, same layer, same hop: reuse the interpolation
-              y[1] = y[0];
-            } else {
-              const bool valid = (unsigned)q[e] < (unsigned)nprb[e];
-              int hi = ro[e], lo = ro[e] - 1;
-              if (q[e] == nprb[e] - 1 && tail_r[e]) lo = hi = n_re - 1;  // at/after the last pilot: hold (T:316,321)
-              lo = lo < 0 ? 0 : lo;                                       // at/before the first pilot: hold (T:315,320)
-              if (!valid) lo = hi = 0;
-              const float2 u = Pe[e][lo], v = Pe[e][hi];
-              y[e] = valid ? make_float2(u.x + al[e] * (v.x - u.x), u.y + al[e] * (v.y - u.y)) : make_float2(0.f, 0.f);
-              q[e] += QS;
-              ro[e] += dro[e];
-            }
-          }
-          const float2 ya = cmul(y[0], rsel[0]), yb = cmul(y[1], rsel[1]);
-          store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
-          o += ACTIVE;
-        }
-      }
+      write_grid_direct<L, NH>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);
     } else {
       const float2* HA = scratch + ((hsel[0] * L + lsel[0]) << ch_log2);
       const float2* HB = scratch + ((hsel[1] * L + lsel[1]) << ch_log2);
 #pragma unroll 1
-      for (int c0 = 0; c0 < plan->n_sc; c0 += CH) {
-        const int cn = min(CH, plan->n_sc - c0);
+      for (int c0 = 0; c0 < lp->n_sc; c0 += CH) {
+        const int cn = min(CH, lp->n_sc - c0);
         for (int i = tid; i < NH * L * CH; i += NT) {
           const int s = i & (CH - 1), hl = i >> ch_log2;
           if (s < cn) {
             const int h = hl / L, l = hl - h * L;
-            const int p = c0 + s - plan->hop[h].sc0;
+            const int p = c0 + s - lp->hop[h].sc0;
             float2 v = make_float2(0.f, 0.f);
-            if (p >= 0 && p < plan->hop[h].n_sc_hop) v = interp_at(h, l, p);
+            if (p >= 0 && p < lp->hop[h].n_sc_hop) v = interp_at(h, l, p);
             scratch[i] = v;
           }
         }
@@ -1154,9 +1181,9 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
       float2 val = make_float2(0.f, 0.f);
 #pragma unroll
       for (int h = NH - 1; h >= 0; --h) {
-        const CeDevHop& hp = plan->hop[h];
-        const int p = sc - hp.sc0;
-        if (sym >= hp.sym0 && sym < hp.sym1 && p >= 0 && p < hp.n_sc_hop) {
+        const CeDevHop& lh = lp->hop[h];
+        const int p = sc - lh.sc0;
+        if (sym >= lh.sym0 && sym < lh.sym1 && p >= 0 && p < lh.n_sc_hop) {
           val = interp_at(h, l, p);
           if (apply_rot) val = cmul(val, rot_final[sym]);
           break;
@@ -1200,7 +1227,7 @@ namespace {
 template <int L, int NH, int ND>
 int launch_t(const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv, const float2* tw,
              const CeKernelArgs& args, int lds, int grid_cap, hipStream_t stream) {
-  const unsigned grid = (unsigned)((!CE_PERSIST || args.n_items < grid_cap) ? args.n_items : grid_cap);
+  const unsigned grid = (unsigned)((!CE_PERSIST || args.n_local < grid_cap) ? args.n_local : grid_cap);
   hipLaunchKernelGGL((ce_estimate_kernel<L, NH, ND>), dim3(grid), dim3(NT), lds, stream, dplan, re_idx, ta_inv, tw,
                      args);
   return (int)hipGetLastError();

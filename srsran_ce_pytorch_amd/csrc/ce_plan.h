@@ -76,11 +76,12 @@ struct CeKernelArgs {
   double *noise, *rsrp, *epre, *ta, *cfo;
   int64_t n_items;
   int32_t n_ports;
+  int64_t item0, n_local;  // a launch covers work items [item0, item0 + n_local) of the n_items batch
 };
 
 // LDS carve-up shared by host (sizing) and device (offsets); all offsets multiples of 16 B.
 struct CeLdsLayout {
-  int32_t off_p, off_scratch, off_red, off_rot, off_tab, off_misc, off_tw, off_rcz, total;
+  int32_t off_p, off_scratch, off_red, off_rot, off_tab, off_misc, off_tw, off_rcz, off_plan, total;
 };
 
 static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_layers, int n_re_pad, int scratch_bytes) {
@@ -94,6 +95,7 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
   l.off_misc = o;     o += 56 * 8;                               // doubles: cfo_hop[2], pad[2], sst[16], sst_dmrs[2][14], TA arg-max keys[8]
   l.off_tw = o;       o += (256 + 16) * 8;                       // W256^j, W4096^i for the TA transform
   l.off_rcz = o;      o += ((CE_RCZ_LEN + 1) & ~1) * 8;          // zero-padded RC taps (float64)
+  l.off_plan = o;     o += (int)((sizeof(CeDevPlan) + 15) & ~15); // LDS copy of the plan (no scalar loads from global later)
   l.total = (o + 15) & ~15;
   return l;
 }
@@ -101,3 +103,4 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
 int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,
               const float2* tw, const CeKernelArgs& args, int lds_bytes, int grid_cap, hipStream_t stream);
 int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int lds_bytes, int* blocks_per_cu);
+
