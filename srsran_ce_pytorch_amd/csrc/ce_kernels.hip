@@ -349,6 +349,7 @@ template <int PAD>
 __device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils, int pad_rt, const double* rcz,
                                                 float2* vpb, int tid, double vmx, double vin, double vid) {
   constexpr int CV = CE_CONV_C, NCV = NT - 64, NTAP = 2 * PAD + 1;
+  static_assert(CV == 9, "the ordering asm below names the nine accumulators");
   // rc_ext[j], j = 0..NTAP-1: the actual taps centred in the PAD-wide template (zeros outside)
   const double* rc = rcz + (CV - 1) - (PAD - pad_rt);
   const int m0 = tid * CV;
@@ -393,6 +394,13 @@ __device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils
     for (int w = 0; w < CV + 2 * PAD; ++w) {
       int idx = m0 - PAD + w;
       idx = idx < 0 ? 0 : (idx >= n_re ? n_re - 1 : idx);  // clamped reads only feed outputs the last wave overwrites
+      // Order this sample's LDS read after the previous samples' MACs (the address becomes known only here, the
+      // accumulators pass through the same statement).  Left alone, the optimizer hoists all CV+2*PAD reads and
+      // their float64 conversions (4 VGPRs a sample, 92 in all) above the first MAC.
+      if ((w & 1) == 0) {
+        asm volatile("" : "+v"(idx), "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]), "+v"(ar[7]), "+v"(ar[8]));
+        asm volatile("" : "+v"(idx), "+v"(ai[0]), "+v"(ai[1]), "+v"(ai[2]), "+v"(ai[3]), "+v"(ai[4]), "+v"(ai[5]), "+v"(ai[6]), "+v"(ai[7]), "+v"(ai[8]));
+      }
       const float2 x = Pl[idx];
       const double dx = (double)x.x, dy = (double)x.y;
 #pragma unroll
@@ -403,9 +411,6 @@ __device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils
           ai[o] += h[j <= PAD ? j : 2 * PAD - j] * dy;
         }
       }
-      // keep at most a few window samples in flight: unfenced, the scheduler hoists all CV+2*PAD LDS reads
-      // (2 VGPRs each) above the first MAC
-      if ((w & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();
