@@ -11,6 +11,7 @@ Workloads (BASELINE.json configs):
                         reference's own frequency smoothing (it has no MMSE/Wiener mode).
                         This is the configuration the metric ("273-PRB PUSCH, 4 Rx") is quoted on.
   pusch273_1rx_none     configs[1]: LS + linear interpolation, 273 PRB / 1 Rx / 1024 slots.
+  pusch273_4rx_mmse     EXTENSION (parity unpinned): block LMMSE/Wiener smoothing on f32 MFMA instead of the RC FIR.
   pusch273_4rx_cnn      configs[4]: the ce_dl_cnn.py variant (fixed-weight 1-D in-painting instead of linear
                         interpolation; the reference has no Conv2d / fp16 / learned weights).
 
@@ -37,6 +38,9 @@ WORKLOADS = {
     "pusch273_1rx_none": dict(smoothing="none", ports=1, slots=1024),
     # configs[4] as the reference actually implements it: ce_dl_cnn's fixed 3-tap in-painting
     "pusch273_4rx_cnn": dict(smoothing="filter", ports=4, slots=8192, interp="cnn"),
+    # configs[2] as BASELINE.json words it ("MMSE Wiener filter on"): an EXTENSION -- the reference has no such mode
+    # (SURVEY 0.4), its only oracle is the build's own numpy restatement => parity unpinned, reported separately
+    "pusch273_4rx_mmse": dict(smoothing="mmse", ports=4, slots=8192),
 }
 
 

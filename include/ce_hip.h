@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CE_ABI_VERSION 1
+#define CE_ABI_VERSION 2
 
 #define CE_MAX_LAYERS 4   /* Tx layers (pilots.shape[2]); 2 per CDM group (T:551-552) */
 #define CE_MAX_CDM 2
@@ -30,8 +30,12 @@ extern "C" {
 #define CE_MAX_SYMBOLS 14 /* the reference's CFO ramp assumes a 14-symbol slot (T:928-929) */
 #define CE_FFT_SIZE 4096  /* time-alignment IFFT length (T:677) */
 
-/* config.Smoothing (T:633-668) */
-enum { CE_SMOOTH_NONE = 0, CE_SMOOTH_MEAN = 1, CE_SMOOTH_FILTER = 2 };
+/* config.Smoothing (T:633-668).  CE_SMOOTH_MMSE is an EXTENSION with no counterpart in the reference ("parity
+ * unpinned", its only oracle is oracle/ce_oracle.py::smooth_mmse): block-wise LMMSE / Wiener smoothing over
+ * CE_MMSE_BLOCK consecutive pilots, W = R (R + nsr I)^-1, R from a uniform power-delay profile on [0, tau];
+ * the complex 32x32 filter is applied to all blocks of a work item as f32 MFMA (v_mfma_f32_16x16x4_f32) tiles. */
+enum { CE_SMOOTH_NONE = 0, CE_SMOOTH_MEAN = 1, CE_SMOOTH_FILTER = 2, CE_SMOOTH_MMSE = 3 };
+#define CE_MMSE_BLOCK 32
 /* frequency interpolation: T:311-340 (linear) or src/ce_dl_cnn.py:276-295, 473-508 (fixed 3-tap partial-convolution
  * in-painting + two low-pass passes; also enables the CNNSmoothingAlpha blend of src/ce_dl_cnn.py:712-715) */
 enum { CE_INTERP_LINEAR = 0, CE_INTERP_CNN = 1 };
@@ -71,6 +75,8 @@ typedef struct ce_plan_desc {
   double beta_dmrs;      /* betaDMRS */
   double cp_ms[CE_MAX_SYMBOLS]; /* config.CyclicPrefixDurations[0:14], milliseconds */
   double cnn_smoothing_alpha;   /* config.CNNSmoothingAlpha (src/ce_dl_cnn.py:864); 0 = off */
+  double mmse_delay_spread_s;   /* CE_SMOOTH_MMSE: tau, seconds (extension) */
+  double mmse_noise_to_signal;  /* CE_SMOOTH_MMSE: nsr (extension) */
   ce_hop_desc hop[CE_MAX_HOPS];
 } ce_plan_desc;
 
@@ -100,6 +106,7 @@ typedef struct ce_plan_host_view {
   double sst[CE_MAX_SYMBOLS];                     /* symbolStartTime (T:809-820) */
   double two_pi_nsamples[CE_MAX_HOPS];            /* 2*pi*nSamples (T:418-426) */
   double n_pilots, noise_den;                     /* T:901-915 */
+  float mmse_w[2][CE_MMSE_BLOCK][CE_MMSE_BLOCK];  /* CE_SMOOTH_MMSE: Re / Im of W[m][k] */
 } ce_plan_host_view;
 
 /* Same validation and float64 derivation as ce_plan_create but touches no GPU: usable on a CPU-only host. */

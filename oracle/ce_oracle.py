@@ -242,6 +242,46 @@ def fill_ch_est_cdm(channel: np.ndarray, estimated: np.ndarray, hop: HopConfig, 
 
 
 # --------------------------------------------------------------------------------------
+# EXTENSION (no counterpart in the reference -> "parity unpinned"): block-wise LMMSE / Wiener frequency
+# smoothing, Smoothing="mmse".  This restatement is the only oracle the GPU path has for it.
+#   model     y_k = h_k + n_k at the pilot REs; channel taps uniformly spread over [0, tau]:
+#             r(d) = E[h(f+d) h(f)*] = sinc(d*tau) * exp(-j*pi*d*tau)   (d in Hz, r(0) = 1)
+#   filter    W = R (R + nsr*I)^-1 over blocks of MMSE_BLOCK consecutive pilots (the last block is anchored at
+#             the band end and only supplies the outputs the previous blocks did not); nsr = noise-to-signal ratio
+# --------------------------------------------------------------------------------------
+MMSE_BLOCK = 32
+
+
+def mmse_matrix(pilot_sc: np.ndarray, scs_hz: float, tau_s: float, nsr: float) -> np.ndarray:
+    """W (M x M, complex128) for pilots at subcarrier indices ``pilot_sc`` (one block)."""
+    d = (pilot_sc[:, None] - pilot_sc[None, :]).astype(np.float64) * float(scs_hz)
+    r = np.sinc(d * tau_s) * np.exp(-1j * math.pi * d * tau_s)
+    return r @ np.linalg.inv(r + nsr * np.eye(pilot_sc.size))
+
+
+def smooth_mmse(col: np.ndarray, pilot_sc: np.ndarray, scs_hz: float, tau_s: float, nsr: float) -> np.ndarray:
+    n = col.size
+    m = min(MMSE_BLOCK, n)
+    w = mmse_matrix(pilot_sc[:m], scs_hz, tau_s, nsr).astype(np.complex64)
+    nb = -(-n // m)
+    out = np.empty_like(col)
+    for b in range(nb):
+        s0 = min(b * m, n - m)
+        y = (w.astype(np.complex128) @ col[s0: s0 + m].astype(np.complex128)).astype(col.dtype)
+        lo = b * m
+        out[lo: s0 + m] = y[lo - s0:]
+    return out
+
+
+def mmse_params(config, cp_ms: np.ndarray):
+    """(tau_s, nsr): MMSEDelaySpread defaults to the normal cyclic prefix (CyclicPrefixDurations[1], ms)."""
+    tau = getattr(config, "MMSEDelaySpread", None)
+    tau = float(cp_ms[1]) * 1e-3 if tau is None else float(tau)
+    nsr = getattr(config, "MMSENoiseToSignal", None)
+    return tau, (0.01 if nsr is None else float(nsr))
+
+
+# --------------------------------------------------------------------------------------
 # One hop (T:495-739) and the slot-level driver (T:745-937)
 # --------------------------------------------------------------------------------------
 def smooth_filter_column(col: np.ndarray, rc: np.ndarray, n_pils: int) -> np.ndarray:
@@ -255,7 +295,7 @@ def smooth_filter_column(col: np.ndarray, rc: np.ndarray, n_pils: int) -> np.nda
 
 def process_hop(hop: HopConfig, pilots: np.ndarray, smoothing: str, rg: np.ndarray, scs: float,
                 cp_ms: np.ndarray, cfo_compensate: bool, beta: float, sst: np.ndarray,
-                channel: np.ndarray, interp: str = "linear", cnn_alpha: float = 0.0):
+                channel: np.ndarray, interp: str = "linear", cnn_alpha: float = 0.0, mmse_cfg=None):
     """Returns (epre, cfo_hop|None, ta, noise, rsrp) contributions of this hop; fills ``channel``."""
     pilots = _c64(pilots)
     n_re, n_dmrs, n_layers = pilots.shape
@@ -301,6 +341,11 @@ def process_hop(hop: HopConfig, pilots: np.ndarray, smoothing: str, rg: np.ndarr
                 a = float(max(0.0, min(1.0, cnn_alpha)))
                 sm = (sm + a * (cnn_lowpass(sm, passes=1) - sm)).astype(p.dtype)
             p[:, il] = sm
+    elif smoothing == "mmse":                                         # extension, see mmse_matrix()
+        tau, nsr = mmse_cfg
+        for il in range(n_layers):
+            sc_l = np.flatnonzero(np.kron(mask_prbs, re_mask[:, il // 2]))
+            p[:, il] = smooth_mmse(p[:, il].copy(), sc_l, scs, tau, nsr)
     elif smoothing != "none":
         raise ValueError(f"Unknown smoothing strategy {smoothing}.")
 
@@ -349,10 +394,11 @@ def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1: HopConfig, hop2:
     cnn_alpha = float(getattr(config, "CNNSmoothingAlpha", 0.0) or 0.0)
     sst = symbol_start_time(cp_ms, scs) if cfo_compensate else np.zeros((0,))
 
+    mmse_cfg = mmse_params(config, cp_ms) if smoothing == "mmse" else None
     channel = np.zeros((rg.shape[0], rg.shape[1], n_layers), rg.dtype)
     n1 = int(np.asarray(hop1.DMRSsymbols, bool).sum())
     epre, cfo, ta, noise, rsrp = process_hop(hop1, pilots[:, :n1, :], smoothing, rg, scs, cp_ms,
-                                             cfo_compensate, float(beta_dmrs), sst, channel, interp, cnn_alpha)
+                                             cfo_compensate, float(beta_dmrs), sst, channel, interp, cnn_alpha, mmse_cfg)
     all_dmrs = np.asarray(hop1.DMRSsymbols, bool).copy()
     h2 = np.asarray(hop2.DMRSsymbols)
     has_hop2 = h2.size != 0 and int(h2.astype(np.int64).sum()) != 0
@@ -363,7 +409,7 @@ def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1: HopConfig, hop2:
         assert np.array_equal(np.asarray(hop1.DMRSREmask), np.asarray(hop2.DMRSREmask)), \
             "The DM-RS mask should be the same for the two hops."
         e2, c2, t2, n2, r2 = process_hop(hop2, pilots[:, n1:, :], smoothing, rg, scs, cp_ms,
-                                         cfo_compensate, float(beta_dmrs), sst, channel, interp, cnn_alpha)
+                                         cfo_compensate, float(beta_dmrs), sst, channel, interp, cnn_alpha, mmse_cfg)
         epre, ta, noise, rsrp = epre + e2, ta + t2, noise + n2, rsrp + r2
         if c2 is not None:
             cfo = (cfo + c2) / 2 if cfo is not None else c2          # T:605-609

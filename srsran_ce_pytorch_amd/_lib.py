@@ -17,9 +17,9 @@ INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = Path(os.environ.get("CE_HIP_LIB", CSRC / "libce_hip.so"))   # override: diagnostic builds (tools/)
 SOURCES = ["ce_api.hip", "ce_kernels.hip"]
 
-CE_ABI_VERSION = 1
+CE_ABI_VERSION = 2
 CE_MAX_CDM, CE_MAX_HOPS, CE_MAX_SYMBOLS = 2, 2, 14
-SMOOTHING = {"none": 0, "mean": 1, "filter": 2}
+SMOOTHING = {"none": 0, "mean": 1, "filter": 2, "mmse": 3}   # "mmse": extension, not in the reference
 INTERP = {"linear": 0, "cnn": 1}
 CE_ERR_INVALID, CE_ERR_UNSUPPORTED, CE_ERR_HIP, CE_ERR_NOMEM = -1, -2, -3, -4
 
@@ -35,7 +35,8 @@ class PlanDesc(C.Structure):
                 ("n_layers", C.c_int32), ("n_hops", C.c_int32), ("smoothing", C.c_int32),
                 ("cfo_compensate", C.c_int32), ("interp", C.c_int32), ("reserved0", C.c_int32),
                 ("scs_hz", C.c_double), ("beta_dmrs", C.c_double), ("cp_ms", C.c_double * CE_MAX_SYMBOLS),
-                ("cnn_smoothing_alpha", C.c_double), ("hop", HopDesc * CE_MAX_HOPS)]
+                ("cnn_smoothing_alpha", C.c_double), ("mmse_delay_spread_s", C.c_double),
+                ("mmse_noise_to_signal", C.c_double), ("hop", HopDesc * CE_MAX_HOPS)]
 
 
 class PlanInfo(C.Structure):
@@ -53,7 +54,7 @@ class PlanHostView(C.Structure):
                 ("r_ord", ((C.c_int32 * 12) * CE_MAX_CDM) * CE_MAX_HOPS),
                 ("alpha", ((C.c_float * 12) * CE_MAX_CDM) * CE_MAX_HOPS),
                 ("rc", C.c_double * 31), ("sst", C.c_double * CE_MAX_SYMBOLS), ("two_pi_nsamples", C.c_double * CE_MAX_HOPS),
-                ("n_pilots", C.c_double), ("noise_den", C.c_double)]
+                ("n_pilots", C.c_double), ("noise_den", C.c_double), ("mmse_w", ((C.c_float * 32) * 32) * 2)]
 
 
 EXPORTS = ["ce_plan_create", "ce_plan_destroy", "ce_plan_get_info", "ce_plan_derive_host", "ce_estimate_batch",

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <complex>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,7 @@ struct ce_plan {
   ce_plan_info info;
   int device = 0;
   int grid_cap = 1;   // persistent grid: CUs x workgroups resident per CU
+  std::vector<float> mmse_w;  // extension: Re | Im of W[m][k], CE_MMSE_BLOCK^2 each
 };
 
 namespace {
@@ -71,6 +73,54 @@ std::vector<double> rc_taps(int stride, int n_rbs) {
 
 int popcount12(unsigned m) { return __builtin_popcount(m & 0xFFFu); }
 
+// EXTENSION (CE_SMOOTH_MMSE): W = R (R + nsr I)^-1 for one block of m pilots at subcarriers sc[0..m), R from a
+// uniform power-delay profile on [0, tau]: r(d) = sinc(d tau) exp(-j pi d tau), d = (sc_i - sc_j) * scs.
+// A = R + nsr I is Hermitian, so W = (A^-1 R)^H: solve A Z = R by LU with partial pivoting, W = Z^H.
+// w_out: Re then Im, each [CE_MMSE_BLOCK][CE_MMSE_BLOCK] row-major W[row m][col k], zero-padded.
+bool mmse_matrix(const uint16_t* sc, int m, double scs, double tau, double nsr, float* w_out) {
+  typedef std::complex<double> cd;
+  std::vector<cd> A((size_t)m * m), Z((size_t)m * m);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) {
+      const double x = (double)((int)sc[i] - (int)sc[j]) * scs * tau;
+      const double sinc = (x == 0.0) ? 1.0 : sin(M_PI * x) / (M_PI * x);
+      const cd r = sinc * std::exp(cd(0.0, -M_PI * x));
+      Z[(size_t)i * m + j] = r;
+      A[(size_t)i * m + j] = r + (i == j ? nsr : 0.0);
+    }
+  for (int c = 0; c < m; ++c) {  // forward elimination on [A | Z]
+    int piv = c;
+    for (int r = c + 1; r < m; ++r)
+      if (std::abs(A[(size_t)r * m + c]) > std::abs(A[(size_t)piv * m + c])) piv = r;
+    if (std::abs(A[(size_t)piv * m + c]) < 1e-300) return false;
+    if (piv != c)
+      for (int j = 0; j < m; ++j) { std::swap(A[(size_t)c * m + j], A[(size_t)piv * m + j]); std::swap(Z[(size_t)c * m + j], Z[(size_t)piv * m + j]); }
+    const cd inv = 1.0 / A[(size_t)c * m + c];
+    for (int r = c + 1; r < m; ++r) {
+      const cd f = A[(size_t)r * m + c] * inv;
+      if (f == cd(0.0)) continue;
+      for (int j = c; j < m; ++j) A[(size_t)r * m + j] -= f * A[(size_t)c * m + j];
+      for (int j = 0; j < m; ++j) Z[(size_t)r * m + j] -= f * Z[(size_t)c * m + j];
+    }
+  }
+  for (int c = m - 1; c >= 0; --c) {  // back substitution
+    const cd inv = 1.0 / A[(size_t)c * m + c];
+    for (int j = 0; j < m; ++j) {
+      cd v = Z[(size_t)c * m + j];
+      for (int k = c + 1; k < m; ++k) v -= A[(size_t)c * m + k] * Z[(size_t)k * m + j];
+      Z[(size_t)c * m + j] = v * inv;
+    }
+  }
+  memset(w_out, 0, sizeof(float) * 2 * CE_MMSE_BLOCK * CE_MMSE_BLOCK);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) {  // W = Z^H
+      const cd w = std::conj(Z[(size_t)j * m + i]);
+      w_out[i * CE_MMSE_BLOCK + j] = (float)w.real();
+      w_out[CE_MMSE_BLOCK * CE_MMSE_BLOCK + i * CE_MMSE_BLOCK + j] = (float)w.imag();
+    }
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -87,7 +137,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (d->n_prb_grid < 1 || 12 * d->n_prb_grid > CE_FFT_SIZE)
     return fail(CE_ERR_UNSUPPORTED, "grid of %d PRB: the time-alignment IFFT (T:679) needs 12*n_prb <= %d", d->n_prb_grid, CE_FFT_SIZE);
   if (d->n_sym < 1 || d->n_sym > CE_MAX_SYMBOLS) return fail(CE_ERR_UNSUPPORTED, "n_sym=%d outside 1..%d", d->n_sym, CE_MAX_SYMBOLS);
-  if (d->smoothing < CE_SMOOTH_NONE || d->smoothing > CE_SMOOTH_FILTER) return fail(CE_ERR_INVALID, "Unknown smoothing strategy %d.", d->smoothing);
+  if (d->smoothing < CE_SMOOTH_NONE || d->smoothing > CE_SMOOTH_MMSE) return fail(CE_ERR_INVALID, "Unknown smoothing strategy %d.", d->smoothing);
   if (d->interp != CE_INTERP_LINEAR && d->interp != CE_INTERP_CNN) return fail(CE_ERR_INVALID, "unknown interp %d", d->interp);
   if (d->interp == CE_INTERP_CNN && d->n_sym != CE_MAX_SYMBOLS) return fail(CE_ERR_UNSUPPORTED, "the in-painting path is built for 14-symbol grids");
   if (!(d->scs_hz > 0) || !(d->beta_dmrs > 0)) return fail(CE_ERR_INVALID, "scs and beta_dmrs must be positive");
@@ -264,12 +314,41 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
                        (int)rc.size() == 15) ? 1 : 0;
   }
 
+  if (d->smoothing == CE_SMOOTH_MMSE) {
+    // every block of CE_MMSE_BLOCK pilots must see the same pilot spacing pattern (one W serves them all)
+    const int m = n_re < CE_MMSE_BLOCK ? n_re : CE_MMSE_BLOCK;
+    P.mmse_nb = (n_re + m - 1) / m;
+    P.mmse_nbp = (P.mmse_nb + 15) & ~15;
+    for (int h = 0; h < d->n_hops; ++h)
+      for (int c = 0; c < n_cdm; ++c) {
+        const uint16_t* sc = re_idx.data() + P.hop[h].re_off[c];
+        for (int b = 0; b < P.mmse_nb; ++b) {
+          const int s0 = b * m < n_re - m ? b * m : n_re - m;
+          for (int i = 0; i < m; ++i)
+            if ((int)sc[s0 + i] - (int)sc[s0] != (int)re_idx[P.hop[0].re_off[0] + i] - (int)re_idx[P.hop[0].re_off[0]]) {
+              delete p;
+              return fail(CE_ERR_UNSUPPORTED, "mmse smoothing needs the same pilot spacing in every block of %d pilots", m);
+            }
+        }
+      }
+    if (!(d->mmse_delay_spread_s >= 0.0) || !(d->mmse_noise_to_signal > 0.0)) { delete p; return fail(CE_ERR_INVALID, "mmse: delay spread must be >= 0 and noise-to-signal > 0"); }
+    p->mmse_w.resize(2 * CE_MMSE_BLOCK * CE_MMSE_BLOCK);
+    if (!mmse_matrix(re_idx.data() + P.hop[0].re_off[0], m, d->scs_hz, d->mmse_delay_spread_s, d->mmse_noise_to_signal, p->mmse_w.data())) {
+      delete p;
+      return fail(CE_ERR_INVALID, "mmse: singular correlation matrix");
+    }
+  }
+
   // LDS scratch: TA residue blocks | virtual-pilot-extended band for the RC FIR | writer's H chunk
   {
     int need = 0;
     for (int h = 0; h < d->n_hops; ++h) need = P.hop[h].ta_nres * CE_TA_ROW * 8 > need ? P.hop[h].ta_nres * CE_TA_ROW * 8 : need;
     if (d->smoothing == CE_SMOOTH_FILTER && P.ext_len * 8 > need) need = P.ext_len * 8;
     if (P.n_hops * L * 256 * 8 > need) need = P.n_hops * L * 256 * 8;
+    if (d->smoothing == CE_SMOOTH_MMSE) {  // W^T (Re, Im) + X^T (Re, Im): [32][32] and [32][nbp] floats each
+      const int mm = (2 * CE_MMSE_BLOCK * CE_MMSE_BLOCK + 2 * CE_MMSE_BLOCK * P.mmse_nbp) * 4;
+      if (mm > need) need = mm;
+    }
     P.scratch_bytes = need;
     if (d->smoothing == CE_SMOOTH_FILTER) {
       P.filt_lpp = need / (P.ext_len * 8);
@@ -315,10 +394,17 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   I.pilot_bytes_per_slot = (int64_t)n_re * n_dmrs_total * L * 8;
 
   // IFFT twiddles exp(+j*2*pi*m/4096), float64 -> float32
-  std::vector<float2> tw(CE_FFT_SIZE);
+  std::vector<float2> tw(CE_FFT_SIZE + CE_MMSE_BLOCK * CE_MMSE_BLOCK);  // + W^T (Re | Im) for the mmse extension
   for (int m = 0; m < CE_FFT_SIZE; ++m) {
     const double a = 2.0 * M_PI * (double)m / (double)CE_FFT_SIZE;
     tw[m] = make_float2((float)cos(a), (float)sin(a));
+  }
+  if (!p->mmse_w.empty()) {
+    float* wt = reinterpret_cast<float*>(tw.data() + CE_FFT_SIZE);  // [2][k][m]
+    for (int part = 0; part < 2; ++part)
+      for (int k = 0; k < CE_MMSE_BLOCK; ++k)
+        for (int m = 0; m < CE_MMSE_BLOCK; ++m)
+          wt[part * CE_MMSE_BLOCK * CE_MMSE_BLOCK + k * CE_MMSE_BLOCK + m] = p->mmse_w[part * CE_MMSE_BLOCK * CE_MMSE_BLOCK + m * CE_MMSE_BLOCK + k];
   }
 
   if (!upload) {  // host-only derivation (ce_plan_derive_host): no HIP call at all
@@ -371,6 +457,7 @@ int ce_plan_derive_host(const ce_plan_desc* d, ce_plan_host_view* v) {
       for (int r = 0; r < 12; ++r) { v->r_ord[h][c][r] = P.hop[h].r_ord[c][r]; v->alpha[h][c][r] = P.hop[h].alpha[c][r]; }
     }
   }
+  if (!p->mmse_w.empty()) memcpy(v->mmse_w, p->mmse_w.data(), sizeof(v->mmse_w));
   delete p;
   return CE_OK;
 }

@@ -69,6 +69,7 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 // flight (s_waitcnt vmcnt(N) after each store, N = 2..16), raised/lowered wave priority around the writer,
 // touching a later work item's DM-RS rows ahead of time -- none faster, the last one 17 % slower.
 __device__ __forceinline__ void store_f4(float4* p, float4 v) { *p = v; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Compiler fence on a register value (no instruction).  Used after the CFO stage so its 14 pilot
 // products are not kept alive (56 VGPRs) for re-use by the LS stage across two barriers.
@@ -786,6 +787,64 @@ __global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeD
           Ph[l * n_re_pad + k] = make_float2((float)(m[2 * l] / (double)n_re), (float)(m[2 * l + 1] / (double)n_re));
       }
       __syncthreads();
+    } else if (lp->smoothing == CE_SMOOTH_MMSE) {
+      // EXTENSION (not in the reference): block LMMSE smoothing.  Y = W X for every block of 32 pilots of the layer
+      // at once: X^T (blocks as columns) and W^T are staged in the scratch, the complex product is four real
+      // v_mfma_f32_16x16x4_f32 chains per 16x16 output tile (A = W: lane -> [m = lane&15][k = lane>>4],
+      // B = X: [k = lane>>4][n = lane&15], C/D: col = lane&15, row = 4*(lane>>4) + reg).
+      constexpr int MB = CE_MMSE_BLOCK;
+      const int nb = lp->mmse_nb, nbp = lp->mmse_nbp;
+      float* Wr = reinterpret_cast<float*>(scratch);
+      float* Wi = Wr + MB * MB;
+      float* Xr = Wi + MB * MB;
+      float* Xi = Xr + MB * nbp;
+      const float* wsrc = reinterpret_cast<const float*>(tw + CE_FFT_SIZE);
+      for (int i = tid; i < 2 * MB * MB; i += NT) Wr[i] = wsrc[i];
+      const int m_eff = n_re < MB ? n_re : MB;
+      const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll 1
+      for (int l = 0; l < L; ++l) {
+        float2* Pl = Ph + l * n_re_pad;
+        for (int i = tid; i < MB * nbp; i += NT) {
+          const int k = i / nbp, n = i - k * nbp;
+          float2 v = make_float2(0.f, 0.f);
+          if (n < nb && k < m_eff) {
+            const int s0 = n * m_eff < n_re - m_eff ? n * m_eff : n_re - m_eff;
+            v = Pl[s0 + k];
+          }
+          Xr[i] = v.x;
+          Xi[i] = v.y;
+        }
+        __syncthreads();
+        for (int nt = wave; nt < nbp / 16; nt += NW) {
+          f32x4 yr[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, yi[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int ks = 0; ks < MB / 4; ++ks) {
+            const int k = ks * 4 + (lane >> 4);
+            const float xr = Xr[k * nbp + nt * 16 + (lane & 15)], xi = Xi[k * nbp + nt * 16 + (lane & 15)];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const float wr = Wr[k * MB + mt * 16 + (lane & 15)], wi = Wi[k * MB + mt * 16 + (lane & 15)];
+              yr[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, xr, yr[mt], 0, 0, 0);
+              yr[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi, -xi, yr[mt], 0, 0, 0);
+              yi[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi, xr, yi[mt], 0, 0, 0);
+              yi[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, xi, yi[mt], 0, 0, 0);
+            }
+          }
+          const int n = nt * 16 + (lane & 15);
+          if (n < nb) {
+            const int s0 = n * m_eff < n_re - m_eff ? n * m_eff : n_re - m_eff;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int m = mt * 16 + (lane >> 4) * 4 + r, idx = s0 + m;
+                if (m < m_eff && idx >= n * m_eff) Pl[idx] = make_float2(yr[mt][r], yi[mt][r]);  // the anchored last block only fills what is left
+              }
+          }
+        }
+        __syncthreads();
+      }
     } else if (lp->smoothing == CE_SMOOTH_FILTER) {
       const int n_pils = lp->n_pils, rc_len = lp->rc_len;
       const int pad = rc_len / 2;

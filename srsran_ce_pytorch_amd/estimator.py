@@ -102,6 +102,11 @@ def build_desc(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_
     scs = float(config.scs)
     beta = float(beta_dmrs)
     alpha = float(getattr(config, "CNNSmoothingAlpha", 0.0) or 0.0)
+    # extension (Smoothing="mmse"): delay spread defaults to the normal cyclic prefix, noise-to-signal to -20 dB
+    mmse_tau = getattr(config, "MMSEDelaySpread", None)
+    mmse_tau = (float(cp[1]) * 1e-3 if cp.size > 1 else 0.0) if mmse_tau is None else float(mmse_tau)
+    mmse_nsr = getattr(config, "MMSENoiseToSignal", None)
+    mmse_nsr = 0.01 if mmse_nsr is None else float(mmse_nsr)
     n_cdm = (n_layers + 1) // 2
 
     d1, r1, m1 = _hop_fields(hop1, n_cdm)
@@ -113,7 +118,7 @@ def build_desc(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_
         assert r1.shape == r2.shape and bool(np.all(r1 == r2)), "The DM-RS mask should be the same for the two hops."
         hops.append((hop2, d2, r2, m2))
 
-    key = (device_index, n_layers, n_prb_grid, n_sym, smoothing, cfo_comp, interp, scs, beta, alpha, cp14.tobytes(),
+    key = (device_index, n_layers, n_prb_grid, n_sym, smoothing, cfo_comp, interp, scs, beta, alpha, mmse_tau, mmse_nsr, cp14.tobytes(),
            tuple((d.tobytes(), r.tobytes(), r.shape, m.tobytes(), int(h.PRBstart), int(h.nPRBs), int(h.startSymbol),
                   int(h.nAllocatedSymbols)) for h, d, r, m in hops))
 
@@ -123,6 +128,7 @@ def build_desc(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_
     desc.n_prb_grid, desc.n_sym, desc.n_layers, desc.n_hops = n_prb_grid, n_sym, n_layers, len(hops)
     desc.smoothing, desc.cfo_compensate, desc.interp = _lib.SMOOTHING[smoothing], int(cfo_comp), _lib.INTERP[interp]
     desc.scs_hz, desc.beta_dmrs, desc.cnn_smoothing_alpha = scs, beta, alpha
+    desc.mmse_delay_spread_s, desc.mmse_noise_to_signal = mmse_tau, mmse_nsr
     for i in range(14):
         desc.cp_ms[i] = cp14[i]
     keep = []

@@ -93,6 +93,28 @@ def test_hip_matches_oracle_random(case):
             check_outputs(ch[it], got, ref[0], rs, TOL_CH, TOL_SC, f"{case['name']}[{it}]/{layout}")
 
 
+MMSE_CASES = [
+    S.case_spec("mmse_273", 273, [S.hop_spec([2, 11], 0, 273)], smoothing="mmse", seed=501),
+    S.case_spec("mmse_25prb", 52, [S.hop_spec([2, 11], 10, 25)], smoothing="mmse", seed=502),
+    S.case_spec("mmse_3prb", 52, [S.hop_spec([2, 11], 10, 3)], smoothing="mmse", seed=503),           # 18 pilots < one block
+    S.case_spec("mmse_L2_2hop", 52, [S.hop_spec([1, 5], 2, 12, 0, 7), S.hop_spec([8, 12], 30, 12, 7, 7)], n_layers=2, smoothing="mmse", seed=504),
+    S.case_spec("mmse_type2_L3", 106, [S.hop_spec([2, 7, 11], 3, 64, re_masks=[S.TYPE2_CDM0, S.TYPE2_CDM1])], n_layers=3, smoothing="mmse", scs=15e3, seed=505),
+]
+
+
+@pytest.mark.parametrize("case", MMSE_CASES, ids=[c["name"] for c in MMSE_CASES])
+def test_hip_mmse_extension_matches_its_oracle(case):
+    """EXTENSION, parity unpinned: Smoothing="mmse" does not exist in the reference; the only check is the
+    build's own numpy restatement (oracle/ce_oracle.py::smooth_mmse).  f32 MFMA vs complex128 matmul: 2e-5."""
+    b = S.build_case(case, 2)
+    b.config.MMSEDelaySpread, b.config.MMSENoiseToSignal = 1.2e-6, 0.03
+    ch, sc = _run_items(b, b.grids, "sym_major")
+    for it in range(2):
+        ref = O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+        got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], sc[4][it]]
+        check_outputs(ch[it], got, ref[0], list(ref[1:]), TOL_CH, TOL_SC, f"{case['name']}[{it}]")
+
+
 def test_non_contiguous_prb_mask():
     """The reference extracts pilots with maskPRBs but fills PRBstart..PRBstart+nPRBs:
     a non-contiguous mask takes the table-lookup paths (pilot positions, TA scatter map)."""

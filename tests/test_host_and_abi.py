@@ -28,10 +28,10 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_struct_layout_matches_header_sizes(lib):
-    # sizes implied by include/ce_hip.h on LP64: hop 14+2*2 (+pad) +8+8(ptr)+8 = 48; plan 40+16+112+8+96 = 272
+    # sizes implied by include/ce_hip.h on LP64: hop 14+2*2 (+pad) +8+8(ptr)+8 = 48; plan 40+16+112+8+16+96 = 288
     import ctypes as C
     assert C.sizeof(_lib.HopDesc) == 48
-    assert C.sizeof(_lib.PlanDesc) == 272
+    assert C.sizeof(_lib.PlanDesc) == 288
     assert C.sizeof(_lib.PlanInfo) == 40
 
 
@@ -143,3 +143,21 @@ def test_host_derivation_register_path_and_limits(lib):
     h1, h2, cfg = S.numpy_hops(S.case_spec("nc", 52, [S.hop_spec([2, 11], 4, 6)]))
     h1.maskPRBs = np.zeros(52, bool); h1.maskPRBs[[4, 5, 6, 20, 21, 22]] = True
     assert E.derive_host(h1, h2, cfg, 1.0, 1, 52, 14).contig[0] == 0
+
+
+def test_mmse_extension_host_filter_matches_oracle(lib):
+    """EXTENSION (parity unpinned: no reference counterpart): the C++ LU solve of W = R (R + nsr I)^-1 against numpy."""
+    for case, L in ((S.bench_case("mmse"), 1), (S.case_spec("m2", 52, [S.hop_spec([2, 11], 4, 3)], smoothing="mmse"), 1),
+                    (S.case_spec("m3", 52, [S.hop_spec([2, 11], 4, 20, re_masks=[S.TYPE2_CDM0])], smoothing="mmse"), 1)):
+        h1, h2, cfg = S.numpy_hops(case)
+        cfg.MMSEDelaySpread, cfg.MMSENoiseToSignal = 1.5e-6, 0.02
+        v = E.derive_host(h1, h2, cfg, 1.0, L, case["n_prb_grid"], 14)
+        sc = np.flatnonzero(np.kron(h1.maskPRBs, h1.DMRSREmask[:, 0]))
+        m = min(32, sc.size)
+        w = O.mmse_matrix(sc[:m], cfg.scs, 1.5e-6, 0.02)
+        got = np.array(v.mmse_w[0])[:m, :m] + 1j * np.array(v.mmse_w[1])[:m, :m]
+        assert np.abs(got - w).max() < 2e-6 * np.abs(w).max()
+        assert not np.array(v.mmse_w[0])[m:].any() and not np.array(v.mmse_w[0])[:, m:].any()
+    h1, h2, cfg = S.numpy_hops(S.case_spec("m4", 52, [S.hop_spec([2, 11], 4, 8, re_masks=[[1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]])], smoothing="mmse"))
+    with pytest.raises(NotImplementedError):      # 5 bunched pilots per PRB, 40 pilots: the anchored last block starts mid-PRB
+        E.derive_host(h1, h2, cfg, 1.0, 1, 52, 14)
