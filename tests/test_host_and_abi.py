@@ -161,3 +161,23 @@ def test_mmse_extension_host_filter_matches_oracle(lib):
     h1, h2, cfg = S.numpy_hops(S.case_spec("m4", 52, [S.hop_spec([2, 11], 4, 8, re_masks=[[1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]])], smoothing="mmse"))
     with pytest.raises(NotImplementedError):      # 5 bunched pilots per PRB, 40 pilots: the anchored last block starts mid-PRB
         E.derive_host(h1, h2, cfg, 1.0, 1, 52, 14)
+
+
+def test_compat_alias_modules_expose_the_reference_names():
+    """`from ce_rule_tensorized import EstimatorConfig, HopConfig, srs_channel_estimator` (validate_all.py:18) and the
+    same from `srs_estimator_torch` (validate_case0.py:12) must resolve to this build with compat/ on the path."""
+    import importlib
+    import sys
+    sys.path.insert(0, str(ROOT / "compat"))
+    try:
+        for mod in ("ce_rule_tensorized", "srs_estimator_torch"):
+            sys.modules.pop(mod, None)
+            m = importlib.import_module(mod)
+            assert m.srs_channel_estimator is E.srs_channel_estimator
+            hop = m.HopConfig(DMRSsymbols=[1] + [0] * 13, DMRSREmask=[[1]] * 12, PRBstart=0, nPRBs=1, maskPRBs=[1], startSymbol=0, nAllocatedSymbols=14)
+            cfg = m.EstimatorConfig(scs=15e3, CyclicPrefixDurations=[0.0] * 14)
+            assert cfg.Smoothing == "filter" and cfg.CFOCompensate is True and hop.nPRBs == 1      # defaults of T:24-29
+    finally:
+        sys.path.remove(str(ROOT / "compat"))
+        for mod in ("ce_rule_tensorized", "srs_estimator_torch"):
+            sys.modules.pop(mod, None)
