@@ -382,6 +382,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
     if (same) P.reg_nd = nd;
   }
+  P.reg_kpt = (n_re <= CE_THREADS && !getenv("CE_FORCE_WIDE")) ? 1 : CE_KPT;  // CE_FORCE_WIDE: tuning knob
   if (getenv("CE_FORCE_GENERIC")) P.reg_nd = 0;  // tuning knob: always take the re-read path
 
   const CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
@@ -421,7 +422,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (e == hipSuccess) e = hipMemcpy(p->dev_re_idx, re_idx.data(), re_idx.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->dev_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
   int blocks_per_cu = 1, n_cu = 1;
-  if (e == hipSuccess) e = (hipError_t)ce_prepare_kernel(L, P.n_hops, P.reg_nd, lay.total, &blocks_per_cu);
+  if (e == hipSuccess) e = (hipError_t)ce_prepare_kernel(L, P.n_hops, P.reg_nd, P.reg_kpt, lay.total, &blocks_per_cu);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device);
   p->grid_cap = blocks_per_cu * n_cu;
   if (e != hipSuccess) {

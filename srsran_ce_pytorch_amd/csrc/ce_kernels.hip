@@ -23,7 +23,6 @@ namespace {
 
 constexpr int NT = CE_THREADS;
 constexpr int NW = NT / 64;
-constexpr int KPT = CE_KPT;
 constexpr double kInvPi = 0.31830988618379067153776752674503;
 
 #ifndef CE_ABLATE
@@ -494,10 +493,13 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
 }
 
 // L layers, NH hops; ND = DM-RS symbols per hop whose pilot REs (and pilots) stay in registers between the CFO,
-// LS and residual stages (needs one CDM group and n_re <= KPT*NT); ND = 0 re-reads them from global memory
+// LS and residual stages (one layer, n_re <= KPT*NT); ND = 0 re-reads them from global memory
 // (L2) in each of the three stages and works for any geometry.
-template <int L, int NH, int ND>
-__global__ __launch_bounds__(NT, CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
+// KPT = pilot REs per thread on the register path: CE_KPT for wide bands, 1 for bands of <= NT pilots (<= 42 PRB at
+// comb 2), whose kernels then need ~50 fewer VGPRs and run four workgroups per CU -- narrow allocations are
+// latency-bound, so residency is what they are short of.
+template <int L, int NH, int ND, int KPT>
+__global__ __launch_bounds__(NT, (KPT == 1 && ND > 0 && NH == 1) ? 4 : CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
                                                          const uint16_t* __restrict__ re_idx,
                                                          const uint16_t* __restrict__ ta_inv,
                                                          const float2* __restrict__ tw, CeKernelArgs a) {
@@ -1288,19 +1290,19 @@ extern "C" int ce_debug_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_
 namespace {
 #endif
 
-template <int L, int NH, int ND>
+template <int L, int NH, int ND, int KPT>
 int launch_t(const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv, const float2* tw,
              const CeKernelArgs& args, int lds, int grid_cap, hipStream_t stream) {
   const unsigned grid = (unsigned)((!CE_PERSIST || args.n_local < grid_cap) ? args.n_local : grid_cap);
-  hipLaunchKernelGGL((ce_estimate_kernel<L, NH, ND>), dim3(grid), dim3(NT), lds, stream, dplan, re_idx, ta_inv, tw,
+  hipLaunchKernelGGL((ce_estimate_kernel<L, NH, ND, KPT>), dim3(grid), dim3(NT), lds, stream, dplan, re_idx, ta_inv, tw,
                      args);
   return (int)hipGetLastError();
 }
 
 // sets the dynamic-LDS limit and reports how many workgroups fit a CU (the persistent grid is CUs x that)
-template <int L, int NH, int ND>
+template <int L, int NH, int ND, int KPT>
 int prepare_t(int lds, int* blocks_per_cu) {
-  const void* fn = reinterpret_cast<const void*>(&ce_estimate_kernel<L, NH, ND>);
+  const void* fn = reinterpret_cast<const void*>(&ce_estimate_kernel<L, NH, ND, KPT>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
   int nb = 0;
@@ -1311,30 +1313,34 @@ int prepare_t(int lds, int* blocks_per_cu) {
 
 }  // namespace
 
-// (layers, hops, register-path DM-RS count): ND in {1,2} only exists for one layer
-#define CE_DISPATCH(FN, ...)                                       \
-  switch (n_layers * 100 + n_hops * 10 + reg_nd) {                 \
-    case 110: return FN<1, 1, 0>(__VA_ARGS__);                     \
-    case 111: return FN<1, 1, 1>(__VA_ARGS__);                     \
-    case 112: return FN<1, 1, 2>(__VA_ARGS__);                     \
-    case 120: return FN<1, 2, 0>(__VA_ARGS__);                     \
-    case 121: return FN<1, 2, 1>(__VA_ARGS__);                     \
-    case 122: return FN<1, 2, 2>(__VA_ARGS__);                     \
-    case 210: return FN<2, 1, 0>(__VA_ARGS__);                     \
-    case 220: return FN<2, 2, 0>(__VA_ARGS__);                     \
-    case 310: return FN<3, 1, 0>(__VA_ARGS__);                     \
-    case 320: return FN<3, 2, 0>(__VA_ARGS__);                     \
-    case 410: return FN<4, 1, 0>(__VA_ARGS__);                     \
-    case 420: return FN<4, 2, 0>(__VA_ARGS__);                     \
-    default: return -1;                                            \
+// (layers, hops, register-path DM-RS count, pilot REs per thread): ND in {1,2} only exists for one layer
+#define CE_DISPATCH(FN, ...)                                                  \
+  switch (n_layers * 1000 + n_hops * 100 + reg_nd * 10 + (reg_nd && reg_kpt == 1)) { \
+    case 1100: return FN<1, 1, 0, CE_KPT>(__VA_ARGS__);                       \
+    case 1110: return FN<1, 1, 1, CE_KPT>(__VA_ARGS__);                       \
+    case 1111: return FN<1, 1, 1, 1>(__VA_ARGS__);                            \
+    case 1120: return FN<1, 1, 2, CE_KPT>(__VA_ARGS__);                       \
+    case 1121: return FN<1, 1, 2, 1>(__VA_ARGS__);                            \
+    case 1200: return FN<1, 2, 0, CE_KPT>(__VA_ARGS__);                       \
+    case 1210: return FN<1, 2, 1, CE_KPT>(__VA_ARGS__);                       \
+    case 1211: return FN<1, 2, 1, 1>(__VA_ARGS__);                            \
+    case 1220: return FN<1, 2, 2, CE_KPT>(__VA_ARGS__);                       \
+    case 1221: return FN<1, 2, 2, 1>(__VA_ARGS__);                            \
+    case 2100: return FN<2, 1, 0, CE_KPT>(__VA_ARGS__);                       \
+    case 2200: return FN<2, 2, 0, CE_KPT>(__VA_ARGS__);                       \
+    case 3100: return FN<3, 1, 0, CE_KPT>(__VA_ARGS__);                       \
+    case 3200: return FN<3, 2, 0, CE_KPT>(__VA_ARGS__);                       \
+    case 4100: return FN<4, 1, 0, CE_KPT>(__VA_ARGS__);                       \
+    case 4200: return FN<4, 2, 0, CE_KPT>(__VA_ARGS__);                       \
+    default: return -1;                                                       \
   }
 
 int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,
               const float2* tw, const CeKernelArgs& args, int lds_bytes, int grid_cap, hipStream_t stream) {
-  const int n_layers = hplan.n_layers, n_hops = hplan.n_hops, reg_nd = hplan.reg_nd;
+  const int n_layers = hplan.n_layers, n_hops = hplan.n_hops, reg_nd = hplan.reg_nd, reg_kpt = hplan.reg_kpt;
   CE_DISPATCH(launch_t, dplan, re_idx, ta_inv, tw, args, lds_bytes, grid_cap, stream)
 }
 
-int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int lds_bytes, int* blocks_per_cu) {
+int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int reg_kpt, int lds_bytes, int* blocks_per_cu) {
   CE_DISPATCH(prepare_t, lds_bytes, blocks_per_cu)
 }

@@ -47,6 +47,7 @@ struct CeDevPlan {
   int32_t n_sc, n_sym, n_layers, n_cdm, n_hops, smoothing, cfo_comp, interp;
   int32_t n_re, n_re_pad, n_pils, rc_len, ext_len, filt_lpp;
   int32_t cfo_estimated, reg_nd;      // reg_nd: DM-RS symbols per hop held in registers (0 = re-read path)
+  int32_t reg_kpt, pad3;              // pilot REs per thread on the register path: 1 (n_re <= CE_THREADS) or CE_KPT
   int32_t scratch_bytes, wr_ch_log2;  // LDS scratch size; log2 of the writer's subcarrier chunk
   float beta_f;
   double beta, scs, denom_cdm, n_pilots, noise_den;
@@ -104,5 +105,5 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
 
 int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,
               const float2* tw, const CeKernelArgs& args, int lds_bytes, int grid_cap, hipStream_t stream);
-int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int lds_bytes, int* blocks_per_cu);
+int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int reg_kpt, int lds_bytes, int* blocks_per_cu);
 
