@@ -382,7 +382,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
     if (same) P.reg_nd = nd;
   }
-  P.reg_kpt = (n_re <= CE_THREADS && !getenv("CE_FORCE_WIDE")) ? 1 : CE_KPT;  // CE_FORCE_WIDE: tuning knob
+  P.reg_kpt = getenv("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : (n_re <= 2 * CE_THREADS ? 2 : CE_KPT));  // env: tuning knob
   if (getenv("CE_FORCE_GENERIC")) P.reg_nd = 0;  // tuning knob: always take the re-read path
 
   const CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);

@@ -495,11 +495,11 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
 // L layers, NH hops; ND = DM-RS symbols per hop whose pilot REs (and pilots) stay in registers between the CFO,
 // LS and residual stages (one layer, n_re <= KPT*NT); ND = 0 re-reads them from global memory
 // (L2) in each of the three stages and works for any geometry.
-// KPT = pilot REs per thread on the register path: CE_KPT for wide bands, 1 for bands of <= NT pilots (<= 42 PRB at
-// comb 2), whose kernels then need ~50 fewer VGPRs and run four workgroups per CU -- narrow allocations are
-// latency-bound, so residency is what they are short of.
+// KPT = pilot REs per thread on the register path: CE_KPT for wide bands, 1 / 2 for bands of <= NT / 2 NT pilots
+// (<= 42 / 85 PRB at comb 2), whose kernels then need 40-50 fewer VGPRs and run four workgroups per CU -- narrow
+// allocations are latency-bound, so residency is what they are short of.
 template <int L, int NH, int ND, int KPT>
-__global__ __launch_bounds__(NT, (KPT == 1 && ND > 0 && NH == 1) ? 4 : CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
+__global__ __launch_bounds__(NT, (KPT <= 2 && ND > 0 && NH == 1) ? 4 : CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
                                                          const uint16_t* __restrict__ re_idx,
                                                          const uint16_t* __restrict__ ta_inv,
                                                          const float2* __restrict__ tw, CeKernelArgs a) {
@@ -1315,17 +1315,21 @@ int prepare_t(int lds, int* blocks_per_cu) {
 
 // (layers, hops, register-path DM-RS count, pilot REs per thread): ND in {1,2} only exists for one layer
 #define CE_DISPATCH(FN, ...)                                                  \
-  switch (n_layers * 1000 + n_hops * 100 + reg_nd * 10 + (reg_nd && reg_kpt == 1)) { \
+  switch (n_layers * 1000 + n_hops * 100 + reg_nd * 10 + (reg_nd ? (reg_kpt <= 2 ? reg_kpt : 0) : 0)) { \
     case 1100: return FN<1, 1, 0, CE_KPT>(__VA_ARGS__);                       \
     case 1110: return FN<1, 1, 1, CE_KPT>(__VA_ARGS__);                       \
     case 1111: return FN<1, 1, 1, 1>(__VA_ARGS__);                            \
+    case 1112: return FN<1, 1, 1, 2>(__VA_ARGS__);                            \
     case 1120: return FN<1, 1, 2, CE_KPT>(__VA_ARGS__);                       \
     case 1121: return FN<1, 1, 2, 1>(__VA_ARGS__);                            \
+    case 1122: return FN<1, 1, 2, 2>(__VA_ARGS__);                            \
     case 1200: return FN<1, 2, 0, CE_KPT>(__VA_ARGS__);                       \
     case 1210: return FN<1, 2, 1, CE_KPT>(__VA_ARGS__);                       \
     case 1211: return FN<1, 2, 1, 1>(__VA_ARGS__);                            \
+    case 1212: return FN<1, 2, 1, 2>(__VA_ARGS__);                            \
     case 1220: return FN<1, 2, 2, CE_KPT>(__VA_ARGS__);                       \
     case 1221: return FN<1, 2, 2, 1>(__VA_ARGS__);                            \
+    case 1222: return FN<1, 2, 2, 2>(__VA_ARGS__);                            \
     case 2100: return FN<2, 1, 0, CE_KPT>(__VA_ARGS__);                       \
     case 2200: return FN<2, 2, 0, CE_KPT>(__VA_ARGS__);                       \
     case 3100: return FN<3, 1, 0, CE_KPT>(__VA_ARGS__);                       \

@@ -19,6 +19,8 @@ cases = [
     ("L1 cnn in-painting", S.bench_case("filter", 1), "cnn"),
     ("L1 cnn type-2 mask", CS("t2c", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "cnn"),
     ("L1 25 PRB in 52", CS("small", 52, [H([2, 11], 10, 25)]), "linear"),
+    ("L1 66 PRB in 106", CS("mid", 106, [H([2, 11], 20, 66)]), "linear"),
+    ("L1 6 PRB in 52", CS("tiny", 52, [H([2, 11], 10, 6)]), "linear"),
 ]
 dev = torch.device("cuda:0")
 slots, ports = (int(sys.argv[1]) if len(sys.argv) > 1 else 2048), 4
