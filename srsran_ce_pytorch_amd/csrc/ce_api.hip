@@ -375,14 +375,14 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   }
   // register path: one layer (two layers' pilots would spill: measured slower than re-reading), every hop
   // with the same 1 or 2 DM-RS symbols, band fits CE_KPT pilot REs per thread
+  P.reg_kpt = getenv("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : (n_re <= 2 * CE_THREADS ? 2 : CE_KPT));  // env: tuning knob
   P.reg_nd = 0;
   if (L == 1 && n_re <= CE_KPT * CE_THREADS) {
     const int nd = P.hop[0].n_dmrs;
-    bool same = nd <= 2;
+    bool same = nd <= (P.reg_kpt <= 2 ? 4 : 2);   // 3-4 DM-RS symbols only fit the registers of the narrow-band kernels
     for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
     if (same) P.reg_nd = nd;
   }
-  P.reg_kpt = getenv("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : (n_re <= 2 * CE_THREADS ? 2 : CE_KPT));  // env: tuning knob
   if (getenv("CE_FORCE_GENERIC")) P.reg_nd = 0;  // tuning knob: always take the re-read path
 
   const CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);

@@ -1313,7 +1313,8 @@ int prepare_t(int lds, int* blocks_per_cu) {
 
 }  // namespace
 
-// (layers, hops, register-path DM-RS count, pilot REs per thread): ND in {1,2} only exists for one layer
+// (layers, hops, register-path DM-RS count, pilot REs per thread): ND > 0 only exists for one layer, ND in {3,4}
+// only for the narrow-band instantiations (KPT 1 or 2), where 3-4 symbols of pilots still fit the registers
 #define CE_DISPATCH(FN, ...)                                                  \
   switch (n_layers * 1000 + n_hops * 100 + reg_nd * 10 + (reg_nd ? (reg_kpt <= 2 ? reg_kpt : 0) : 0)) { \
     case 1100: return FN<1, 1, 0, CE_KPT>(__VA_ARGS__);                       \
@@ -1330,6 +1331,14 @@ int prepare_t(int lds, int* blocks_per_cu) {
     case 1220: return FN<1, 2, 2, CE_KPT>(__VA_ARGS__);                       \
     case 1221: return FN<1, 2, 2, 1>(__VA_ARGS__);                            \
     case 1222: return FN<1, 2, 2, 2>(__VA_ARGS__);                            \
+    case 1131: return FN<1, 1, 3, 1>(__VA_ARGS__);                            \
+    case 1132: return FN<1, 1, 3, 2>(__VA_ARGS__);                            \
+    case 1141: return FN<1, 1, 4, 1>(__VA_ARGS__);                            \
+    case 1142: return FN<1, 1, 4, 2>(__VA_ARGS__);                            \
+    case 1231: return FN<1, 2, 3, 1>(__VA_ARGS__);                            \
+    case 1232: return FN<1, 2, 3, 2>(__VA_ARGS__);                            \
+    case 1241: return FN<1, 2, 4, 1>(__VA_ARGS__);                            \
+    case 1242: return FN<1, 2, 4, 2>(__VA_ARGS__);                            \
     case 2100: return FN<2, 1, 0, CE_KPT>(__VA_ARGS__);                       \
     case 2200: return FN<2, 2, 0, CE_KPT>(__VA_ARGS__);                       \
     case 3100: return FN<3, 1, 0, CE_KPT>(__VA_ARGS__);                       \

@@ -77,6 +77,10 @@ RANDOM_CASES = [
                                     S.hop_spec([8, 12], 30, 9, 7, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1])], n_layers=4, seed=104),
     S.case_spec("rnd_type2_L2", 52, [S.hop_spec([3, 10], 5, 13, re_masks=[S.TYPE2_CDM0])], n_layers=2, seed=105),
     S.case_spec("rnd_106prb_scs15", 106, [S.hop_spec([2, 11], 0, 106)], scs=15e3, seed=106),
+    # 3-4 DM-RS symbols on narrow / mid bands: the register path of the KPT=1/2 kernels
+    S.case_spec("rnd_4dmrs_20prb", 52, [S.hop_spec([2, 5, 8, 11], 7, 20)], seed=107),
+    S.case_spec("rnd_4dmrs_70prb_mean", 106, [S.hop_spec([0, 4, 8, 12], 30, 70)], smoothing="mean", scs=15e3, seed=108),
+    S.case_spec("rnd_3dmrs_2hop_40prb", 106, [S.hop_spec([0, 3, 6], 2, 40, 0, 7), S.hop_spec([7, 10, 13], 60, 40, 7, 7)], seed=109),
 ]
 
 
