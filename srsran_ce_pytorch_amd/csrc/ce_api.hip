@@ -375,11 +375,13 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   }
   // register path: one layer (two layers' pilots would spill: measured slower than re-reading), every hop
   // with the same 1 or 2 DM-RS symbols, band fits CE_KPT pilot REs per thread
-  P.reg_kpt = getenv("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : (n_re <= 2 * CE_THREADS ? 2 : CE_KPT));  // env: tuning knob
+  P.reg_kpt = getenv("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : n_re <= 2 * CE_THREADS ? 2 : n_re <= 4 * CE_THREADS ? 4 : CE_KPT);  // env: tuning knob
   P.reg_nd = 0;
   if (L == 1 && n_re <= CE_KPT * CE_THREADS) {
     const int nd = P.hop[0].n_dmrs;
-    bool same = nd <= (P.reg_kpt <= 2 ? 4 : 2);   // 3-4 DM-RS symbols only fit the registers of the narrow-band kernels
+    // pilots of nd symbols x reg_kpt REs per thread stay in registers only while the kernel does not spill:
+    // wide kernel 1-2 symbols; narrow-band kernels nd * reg_kpt <= 12 (one hop) / 8 (two hops, ~30 VGPRs dearer)
+    bool same = P.reg_kpt == CE_KPT ? nd <= 2 : (nd <= 4 && nd * P.reg_kpt <= (d->n_hops == 1 ? 12 : 8));
     for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
     if (same) P.reg_nd = nd;
   }

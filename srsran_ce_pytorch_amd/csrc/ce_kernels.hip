@@ -31,6 +31,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_MIN_WAVES
 #define CE_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for (3 workgroups per CU; 4 would spill)
 #endif
+#ifndef CE_MW4_LIMIT
+#define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
+#endif
 #ifndef CE_RELOAD_RESID
 #define CE_RELOAD_RESID 0 // 1: the residual stage re-reads rx / pilots instead of keeping them in registers across smoothing
 #endif
@@ -499,7 +502,7 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
 // (<= 42 / 85 PRB at comb 2), whose kernels then need 40-50 fewer VGPRs and run four workgroups per CU -- narrow
 // allocations are latency-bound, so residency is what they are short of.
 template <int L, int NH, int ND, int KPT>
-__global__ __launch_bounds__(NT, (KPT <= 2 && ND > 0 && NH == 1) ? 4 : CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
+__global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1) ? 4 : CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
                                                          const uint16_t* __restrict__ re_idx,
                                                          const uint16_t* __restrict__ ta_inv,
                                                          const float2* __restrict__ tw, CeKernelArgs a) {
@@ -1313,39 +1316,27 @@ int prepare_t(int lds, int* blocks_per_cu) {
 
 }  // namespace
 
-// (layers, hops, register-path DM-RS count, pilot REs per thread): ND > 0 only exists for one layer, ND in {3,4}
-// only for the narrow-band instantiations (KPT 1 or 2), where 3-4 symbols of pilots still fit the registers
-#define CE_DISPATCH(FN, ...)                                                  \
-  switch (n_layers * 1000 + n_hops * 100 + reg_nd * 10 + (reg_nd ? (reg_kpt <= 2 ? reg_kpt : 0) : 0)) { \
-    case 1100: return FN<1, 1, 0, CE_KPT>(__VA_ARGS__);                       \
-    case 1110: return FN<1, 1, 1, CE_KPT>(__VA_ARGS__);                       \
-    case 1111: return FN<1, 1, 1, 1>(__VA_ARGS__);                            \
-    case 1112: return FN<1, 1, 1, 2>(__VA_ARGS__);                            \
-    case 1120: return FN<1, 1, 2, CE_KPT>(__VA_ARGS__);                       \
-    case 1121: return FN<1, 1, 2, 1>(__VA_ARGS__);                            \
-    case 1122: return FN<1, 1, 2, 2>(__VA_ARGS__);                            \
-    case 1200: return FN<1, 2, 0, CE_KPT>(__VA_ARGS__);                       \
-    case 1210: return FN<1, 2, 1, CE_KPT>(__VA_ARGS__);                       \
-    case 1211: return FN<1, 2, 1, 1>(__VA_ARGS__);                            \
-    case 1212: return FN<1, 2, 1, 2>(__VA_ARGS__);                            \
-    case 1220: return FN<1, 2, 2, CE_KPT>(__VA_ARGS__);                       \
-    case 1221: return FN<1, 2, 2, 1>(__VA_ARGS__);                            \
-    case 1222: return FN<1, 2, 2, 2>(__VA_ARGS__);                            \
-    case 1131: return FN<1, 1, 3, 1>(__VA_ARGS__);                            \
-    case 1132: return FN<1, 1, 3, 2>(__VA_ARGS__);                            \
-    case 1141: return FN<1, 1, 4, 1>(__VA_ARGS__);                            \
-    case 1142: return FN<1, 1, 4, 2>(__VA_ARGS__);                            \
-    case 1231: return FN<1, 2, 3, 1>(__VA_ARGS__);                            \
-    case 1232: return FN<1, 2, 3, 2>(__VA_ARGS__);                            \
-    case 1241: return FN<1, 2, 4, 1>(__VA_ARGS__);                            \
-    case 1242: return FN<1, 2, 4, 2>(__VA_ARGS__);                            \
-    case 2100: return FN<2, 1, 0, CE_KPT>(__VA_ARGS__);                       \
-    case 2200: return FN<2, 2, 0, CE_KPT>(__VA_ARGS__);                       \
-    case 3100: return FN<3, 1, 0, CE_KPT>(__VA_ARGS__);                       \
-    case 3200: return FN<3, 2, 0, CE_KPT>(__VA_ARGS__);                       \
-    case 4100: return FN<4, 1, 0, CE_KPT>(__VA_ARGS__);                       \
-    case 4200: return FN<4, 2, 0, CE_KPT>(__VA_ARGS__);                       \
-    default: return -1;                                                       \
+// (layers, hops, register-path DM-RS count, pilot REs per thread).  The register path (ND > 0) only exists for one
+// layer; the wide kernel (KPT = CE_KPT, bands up to 298 PRB) holds 1-2 DM-RS symbols of pilots in registers, the
+// narrow-band ones (KPT 1 / 2 / 4: bands up to 42 / 85 / 170 PRB of a comb-2 DM-RS) up to 4 -- as far as they fit
+// the 168 VGPRs of 3 workgroups per CU without spilling (ce_api.hip: reg_nd).
+#define CE_CASE(FN, L, NH, ND, KC, KT, ...) \
+  case L * 1000 + NH * 100 + ND * 10 + KC: return FN<L, NH, ND, KT>(__VA_ARGS__);
+#define CE_NARROW(FN, NH, ND, ...) \
+  CE_CASE(FN, 1, NH, ND, 1, 1, __VA_ARGS__) CE_CASE(FN, 1, NH, ND, 2, 2, __VA_ARGS__)
+#define CE_HOPS(FN, NH, ...)                                                                              \
+  CE_CASE(FN, 1, NH, 0, 0, CE_KPT, __VA_ARGS__) CE_CASE(FN, 1, NH, 1, 0, CE_KPT, __VA_ARGS__)           \
+  CE_CASE(FN, 1, NH, 2, 0, CE_KPT, __VA_ARGS__) CE_NARROW(FN, NH, 1, __VA_ARGS__)                       \
+  CE_NARROW(FN, NH, 2, __VA_ARGS__) CE_NARROW(FN, NH, 3, __VA_ARGS__) CE_NARROW(FN, NH, 4, __VA_ARGS__) \
+  CE_CASE(FN, 1, NH, 1, 4, 4, __VA_ARGS__) CE_CASE(FN, 1, NH, 2, 4, 4, __VA_ARGS__)                     \
+  CE_CASE(FN, 2, NH, 0, 0, CE_KPT, __VA_ARGS__) CE_CASE(FN, 3, NH, 0, 0, CE_KPT, __VA_ARGS__)           \
+  CE_CASE(FN, 4, NH, 0, 0, CE_KPT, __VA_ARGS__)
+#define CE_DISPATCH(FN, ...)                                                                                     \
+  switch (n_layers * 1000 + n_hops * 100 + reg_nd * 10 + (reg_nd && reg_kpt < CE_KPT ? reg_kpt : 0)) {          \
+    CE_HOPS(FN, 1, __VA_ARGS__)                                                                                  \
+    CE_CASE(FN, 1, 1, 3, 4, 4, __VA_ARGS__) /* 3 DM-RS x 4 REs per thread: single hop only (registers) */      \
+    CE_HOPS(FN, 2, __VA_ARGS__)                                                                                  \
+    default: return -1;                                                                                          \
   }
 
 int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,

@@ -80,6 +80,8 @@ RANDOM_CASES = [
     # 3-4 DM-RS symbols on narrow / mid bands: the register path of the KPT=1/2 kernels
     S.case_spec("rnd_4dmrs_20prb", 52, [S.hop_spec([2, 5, 8, 11], 7, 20)], seed=107),
     S.case_spec("rnd_4dmrs_70prb_mean", 106, [S.hop_spec([0, 4, 8, 12], 30, 70)], smoothing="mean", scs=15e3, seed=108),
+    S.case_spec("rnd_3dmrs_150prb", 273, [S.hop_spec([2, 7, 11], 60, 150)], seed=110),                       # KPT=4, ND=3
+    S.case_spec("rnd_2hop_136prb", 273, [S.hop_spec([1, 5], 0, 136, 0, 7), S.hop_spec([8, 12], 137, 136, 7, 7)], seed=111),  # KPT=4, 2 hops
     S.case_spec("rnd_3dmrs_2hop_40prb", 106, [S.hop_spec([0, 3, 6], 2, 40, 0, 7), S.hop_spec([7, 10, 13], 60, 40, 7, 7)], seed=109),
 ]
 
