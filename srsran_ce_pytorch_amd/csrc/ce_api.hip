@@ -379,9 +379,9 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   P.reg_nd = 0;
   if (L == 1 && n_re <= CE_KPT * CE_THREADS) {
     const int nd = P.hop[0].n_dmrs;
-    // pilots of nd symbols x reg_kpt REs per thread stay in registers only while the kernel does not spill:
-    // wide kernel 1-2 symbols; narrow-band kernels nd * reg_kpt <= 12 (one hop) / 8 (two hops, ~30 VGPRs dearer)
-    bool same = P.reg_kpt == CE_KPT ? nd <= 2 : (nd <= 4 && nd * P.reg_kpt <= (d->n_hops == 1 ? 12 : 8));
+    // received pilots of nd symbols x reg_kpt REs per thread stay in registers (the DM-RS symbols too while they
+    // fit, ce_kernels.hip: PREG): up to 4 symbols in the narrow-band kernels, 3 in the wide one
+    bool same = nd <= (P.reg_kpt < CE_KPT ? 4 : 3);
     for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
     if (same) P.reg_nd = nd;
   }

@@ -34,6 +34,23 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_MW4_LIMIT
 #define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
 #endif
+#ifndef CE_NH2_MW2_FROM
+#define CE_NH2_MW2_FROM 15  // two hops: from this many pilot REs x symbols per thread on, 2 workgroups per CU with everything in registers
+#endif
+// Register budget of the register-path kernels by pilot REs x DM-RS symbols per thread (KPT * ND): workgroups per CU
+// the allocator must leave room for, and whether the DM-RS symbols stay in registers next to the received pilots
+// (otherwise the three stages that use them re-read them through L2).  The 3-symbol wide kernel measured 2.93 ms at
+// 2 workgroups per CU with everything in registers vs 3.23 ms at 3 with the symbols re-read (3.6 ms generic path).
+constexpr int ce_min_waves(int nh, int nd, int kpt) {
+  const int n = nd * kpt;
+  if (nd == 0) return CE_MIN_WAVES;
+  if (nh == 1) return n <= CE_MW4_LIMIT ? 4 : n <= 14 ? CE_MIN_WAVES : 2;
+  return n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
+}
+constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
+  const int n = nd * kpt;
+  return nd > 0 && (nh == 1 || n <= 8 || n >= CE_NH2_MW2_FROM);
+}
 #ifndef CE_RELOAD_RESID
 #define CE_RELOAD_RESID 0 // 1: the residual stage re-reads rx / pilots instead of keeping them in registers across smoothing
 #endif
@@ -502,7 +519,7 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
 // (<= 42 / 85 PRB at comb 2), whose kernels then need 40-50 fewer VGPRs and run four workgroups per CU -- narrow
 // allocations are latency-bound, so residency is what they are short of.
 template <int L, int NH, int ND, int KPT>
-__global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1) ? 4 : CE_MIN_WAVES) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
+__global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
                                                          const uint16_t* __restrict__ re_idx,
                                                          const uint16_t* __restrict__ ta_inv,
                                                          const float2* __restrict__ tw, CeKernelArgs a) {
@@ -551,7 +568,11 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
   // NEXT item is requested before the current item's grid is written, so the HBM latency of the only
   // dependent global read hides behind ~367 KB of stores.
   float2 xr[REG ? KPT * ND : 1];
-  float2 pr[REG ? KPT * ND * L : 1];
+  // PREG: the DM-RS symbols stay in registers next to the received pilots; otherwise (3 symbols x CE_KPT REs, or two
+  // hops with more than 8 per thread) the three stages that use them re-read them -- the Rx ports of a slot share
+  // them, so they come from L2
+  constexpr bool PREG = ce_pilots_in_regs(NH, ND, KPT);
+  float2 pr[PREG ? KPT * ND * L : 1];
   auto load_hop = [&](int64_t it, int h) {
     if constexpr (REG) {
       const CeDevHop& hp = plan->hop[h];
@@ -566,7 +587,8 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
           for (int s = 0; s < ND; ++s) {
             xr[i * ND + s] = make_float2(1.f + k * 1e-3f, 0.5f);
 #pragma unroll
-            for (int l = 0; l < L; ++l) pr[(i * ND + s) * L + l] = make_float2(0.7071f, -0.7071f);
+            for (int l = 0; l < L; ++l)
+              if constexpr (PREG) pr[(i * ND + s) * L + l] = make_float2(0.7071f, -0.7071f);
           }
         } else if (k < n_re) {
           // uniform 64-bit base (SGPR pair) + 32-bit per-thread offset: one address VGPR per pilot RE
@@ -580,7 +602,7 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
 #pragma unroll
             for (int l = 0; l < L; ++l) {
               const float2* pil_sl = pil + (hp.pil_sym0 + s) * a.ps_sym + l * a.ps_l;
-              pr[(i * ND + s) * L + l] = pil_sl[po];
+              if constexpr (PREG) pr[(i * ND + s) * L + l] = pil_sl[po];
             }
           }
         } else {
@@ -588,7 +610,8 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
           for (int s = 0; s < ND; ++s) {
             xr[i * ND + s] = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int l = 0; l < L; ++l) pr[(i * ND + s) * L + l] = make_float2(0.f, 0.f);
+            for (int l = 0; l < L; ++l)
+              if constexpr (PREG) pr[(i * ND + s) * L + l] = make_float2(0.f, 0.f);
           }
         }
       }
@@ -618,6 +641,16 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
   const int port = (int)(item - slot * a.n_ports);
   const float2* rx = a.rx + slot * a.rs_b + port * a.rs_r;
   const float2* pil = a.pil + slot * a.ps_b;
+  auto pilot_of = [&](const CeDevHop& hh, int i, int s, int l) -> float2 {  // DM-RS symbol of pilot RE tid + i*NT (register path)
+    if constexpr (PREG) {
+      return pr[(i * ND + s) * L + l];
+    } else {
+      const int k = tid + i * NT;
+      if (k >= n_re) return make_float2(0.f, 0.f);
+      const float2* pil_sl = pil + (hh.pil_sym0 + s) * a.ps_sym + l * a.ps_l;
+      return pil_sl[(unsigned)k * (unsigned)a.ps_re];
+    }
+  };
   double tot_epre = 0.0, tot_noise = 0.0, tot_rsrp = 0.0, tot_ta = 0.0;
   STAMP(0);
 
@@ -650,8 +683,8 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
         for (int i = 0; i < KPT; ++i) {
 #pragma unroll
           for (int l = 0; l < L; ++l) {
-            const float2 r0 = cmul_conj(xr[i * ND], pr[(i * ND) * L + l]);
-            const float2 r1 = cmul_conj(xr[i * ND + 1], pr[(i * ND + 1) * L + l]);
+            const float2 r0 = cmul_conj(xr[i * ND], pilot_of(hp, i, 0, l));
+            const float2 r1 = cmul_conj(xr[i * ND + 1], pilot_of(hp, i, 1, l));
             const float2 in = cmul_conj(r1, r0);  // conj(r0) * r1
             part[2 * l] += in.x;
             part[2 * l + 1] += in.y;
@@ -726,7 +759,7 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
           epre_part += x.x * x.x + x.y * x.y;
           const float2 rn = rot_neg[s];
 #pragma unroll
-          for (int l = 0; l < L; ++l) acc[l] = cadd(acc[l], cmul(cmul_conj(x, pr[(i * ND + s) * L + l]), rn));
+          for (int l = 0; l < L; ++l) acc[l] = cadd(acc[l], cmul(cmul_conj(x, pilot_of(lh, i, s, l)), rn));
         }
         if (k < n_re) {
 #pragma unroll
@@ -940,7 +973,7 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
               const float2 rp = rot_pos[s];
               float2 est = make_float2(0.f, 0.f);
 #pragma unroll
-              for (int l = 0; l < L; ++l) est = cadd(est, cmul(pr[(i * ND + s) * L + l], cmul(hl[l], rp)));
+              for (int l = 0; l < L; ++l) est = cadd(est, cmul(pilot_of(lh, i, s, l), cmul(hl[l], rp)));
               const float dr = xr[i * ND + s].x - beta_f * est.x, di = xr[i * ND + s].y - beta_f * est.y;
               noise_part += dr * dr + di * di;
             }
@@ -1127,7 +1160,7 @@ __global__ __launch_bounds__(NT, (ND > 0 && KPT * ND <= CE_MW4_LIMIT && NH == 1)
 #pragma unroll
       for (int i = 0; i < (REG ? KPT * ND : 1); ++i) xr[i] = make_float2(0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < (REG ? KPT * ND * L : 1); ++i) pr[i] = make_float2(0.f, 0.f);
+      for (int i = 0; i < (PREG ? KPT * ND * L : 1); ++i) pr[i] = make_float2(0.f, 0.f);
     }
   }
 #endif
@@ -1329,12 +1362,13 @@ int prepare_t(int lds, int* blocks_per_cu) {
   CE_CASE(FN, 1, NH, 2, 0, CE_KPT, __VA_ARGS__) CE_NARROW(FN, NH, 1, __VA_ARGS__)                       \
   CE_NARROW(FN, NH, 2, __VA_ARGS__) CE_NARROW(FN, NH, 3, __VA_ARGS__) CE_NARROW(FN, NH, 4, __VA_ARGS__) \
   CE_CASE(FN, 1, NH, 1, 4, 4, __VA_ARGS__) CE_CASE(FN, 1, NH, 2, 4, 4, __VA_ARGS__)                     \
+  CE_CASE(FN, 1, NH, 3, 4, 4, __VA_ARGS__) CE_CASE(FN, 1, NH, 4, 4, 4, __VA_ARGS__)                     \
+  CE_CASE(FN, 1, NH, 3, 0, CE_KPT, __VA_ARGS__)                                                          \
   CE_CASE(FN, 2, NH, 0, 0, CE_KPT, __VA_ARGS__) CE_CASE(FN, 3, NH, 0, 0, CE_KPT, __VA_ARGS__)           \
   CE_CASE(FN, 4, NH, 0, 0, CE_KPT, __VA_ARGS__)
 #define CE_DISPATCH(FN, ...)                                                                                     \
   switch (n_layers * 1000 + n_hops * 100 + reg_nd * 10 + (reg_nd && reg_kpt < CE_KPT ? reg_kpt : 0)) {          \
     CE_HOPS(FN, 1, __VA_ARGS__)                                                                                  \
-    CE_CASE(FN, 1, 1, 3, 4, 4, __VA_ARGS__) /* 3 DM-RS x 4 REs per thread: single hop only (registers) */      \
     CE_HOPS(FN, 2, __VA_ARGS__)                                                                                  \
     default: return -1;                                                                                          \
   }

@@ -82,6 +82,10 @@ RANDOM_CASES = [
     S.case_spec("rnd_4dmrs_70prb_mean", 106, [S.hop_spec([0, 4, 8, 12], 30, 70)], smoothing="mean", scs=15e3, seed=108),
     S.case_spec("rnd_3dmrs_150prb", 273, [S.hop_spec([2, 7, 11], 60, 150)], seed=110),                       # KPT=4, ND=3
     S.case_spec("rnd_2hop_136prb", 273, [S.hop_spec([1, 5], 0, 136, 0, 7), S.hop_spec([8, 12], 137, 136, 7, 7)], seed=111),  # KPT=4, 2 hops
+    S.case_spec("rnd_3dmrs_273prb", 273, [S.hop_spec([2, 7, 11], 0, 273)], seed=112),                        # wide kernel, pilots re-read
+    S.case_spec("rnd_4dmrs_2hop_120prb", 273, [S.hop_spec([0, 2, 4, 6], 5, 120, 0, 7), S.hop_spec([7, 9, 11, 13], 150, 120, 7, 7)], smoothing="none", seed=113),
+    S.case_spec("rnd_3dmrs_2hop_200prb", 273, [S.hop_spec([0, 3, 6], 0, 200, 0, 7), S.hop_spec([7, 10, 13], 73, 200, 7, 7)], smoothing="mean", seed=114),
+    S.case_spec("rnd_2hop_200prb", 273, [S.hop_spec([1, 5], 0, 200, 0, 7), S.hop_spec([8, 12], 73, 200, 7, 7)], seed=115),
     S.case_spec("rnd_3dmrs_2hop_40prb", 106, [S.hop_spec([0, 3, 6], 2, 40, 0, 7), S.hop_spec([7, 10, 13], 60, 40, 7, 7)], seed=109),
 ]
 

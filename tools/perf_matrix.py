@@ -15,6 +15,9 @@ cases = [
     ("L4 2dmrs filter (generic path)", S.bench_case("filter", 4), "linear"),
     ("L1 3dmrs filter (generic path)", CS("d3", 273, [H([2, 7, 11], 0, 273)]), "linear"),
     ("L1 2 hops x 2dmrs", CS("h2", 273, [H([1, 5], 0, 136, 0, 7), H([8, 12], 137, 136, 7, 7)]), "linear"),
+    ("L1 2 hops x 2dmrs 200 PRB", CS("h2w", 273, [H([1, 5], 0, 200, 0, 7), H([8, 12], 73, 200, 7, 7)]), "linear"),
+    ("L1 2 hops x 3dmrs 136 PRB", CS("h2d3", 273, [H([0, 3, 6], 0, 136, 0, 7), H([7, 10, 13], 137, 136, 7, 7)]), "linear"),
+    ("L1 2 hops x 3dmrs 200 PRB", CS("h2d3w", 273, [H([0, 3, 6], 0, 200, 0, 7), H([7, 10, 13], 73, 200, 7, 7)]), "linear"),
     ("L1 type-2 mask filter", CS("t2", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "linear"),
     ("L1 cnn in-painting", S.bench_case("filter", 1), "cnn"),
     ("L1 cnn type-2 mask", CS("t2c", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "cnn"),
@@ -28,7 +31,10 @@ cases = [
 ]
 dev = torch.device("cuda:0")
 slots, ports = (int(sys.argv[1]) if len(sys.argv) > 1 else 2048), 4
+only = sys.argv[2] if len(sys.argv) > 2 else ""   # substring filter on the case name
 for name, case, interp in cases:
+    if only not in name:
+        continue
     h1, h2, cfg = S.numpy_hops(case)
     L = case["n_layers"]
     plan = E.make_plan(h1, h2, cfg, case["beta"], L, case["n_prb_grid"], 14, dev, interp)
