@@ -13,7 +13,7 @@ cases = [
     ("L1 2dmrs mean", S.bench_case("mean", 1), "linear"),
     ("L2 2dmrs filter (register path)", S.bench_case("filter", 2), "linear"),
     ("L4 2dmrs filter (generic path)", S.bench_case("filter", 4), "linear"),
-    ("L1 3dmrs filter (generic path)", CS("d3", 273, [H([2, 7, 11], 0, 273)]), "linear"),
+    ("L1 3dmrs filter (register path)", CS("d3", 273, [H([2, 7, 11], 0, 273)]), "linear"),
     ("L1 2 hops x 2dmrs", CS("h2", 273, [H([1, 5], 0, 136, 0, 7), H([8, 12], 137, 136, 7, 7)]), "linear"),
     ("L1 2 hops x 2dmrs 200 PRB", CS("h2w", 273, [H([1, 5], 0, 200, 0, 7), H([8, 12], 73, 200, 7, 7)]), "linear"),
     ("L1 2 hops x 3dmrs 136 PRB", CS("h2d3", 273, [H([0, 3, 6], 0, 136, 0, 7), H([7, 10, 13], 137, 136, 7, 7)]), "linear"),
