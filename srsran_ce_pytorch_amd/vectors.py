@@ -74,3 +74,213 @@ def compare_at_entries(estimate: np.ndarray, entries: np.ndarray) -> Tuple[float
     the harness's comparison protocol (`validate_all.py:547-561`)."""
     d = estimate[entries["sc"], entries["symbol"], entries["port"]].astype(np.complex128) - entries["value"].astype(np.complex128)
     return float(np.abs(d).max()), float(np.sqrt(np.mean(np.abs(d) ** 2)))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# `port_channel_estimator_test_data.h`: the C++ initializer list that describes every vector set.
+#
+# The real header is not in this container (the vectors are git-ignored upstream), so the grammar below follows
+# what the reference's harness extracts from it (`scripts/validation/validate_all.py:75-263`: enum spellings
+# `subcarrier_spacing::kHzNN`, `cyclic_prefix::X, <first symbol>, <n symbols>`,
+# `port_channel_estimator_fd_smoothing_strategy::X, <cfo flag>, <grid PRBs>`, per-layer pattern blocks holding a
+# 14-entry DM-RS symbol mask, one or two grid-wide PRB masks, an optional hop symbol and a 12-entry RE pattern, and
+# the three `"...N.dat"` file names) -- parsed here structurally (nested brace lists) rather than by position, so
+# either field order inside a pattern block is accepted.  Unverified against a real file: "format unpinned".
+# ----------------------------------------------------------------------------------------------------------------
+import itertools
+import re
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+_TOKEN = re.compile(r'"(?:[^"\\]|\\.)*"|[{},]|[^\s{},"]+')
+_NUM = re.compile(r"[-+]?(?:\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?)[fF]?$")
+
+
+@dataclass
+class VectorLayerPattern:
+    dmrs_symbols: np.ndarray          # (n_sym,) bool
+    prb_masks: List[np.ndarray]       # one mask, or two when the layer hops
+    hop_symbol: Optional[int]
+    re_pattern: np.ndarray            # (12,) bool
+
+
+@dataclass
+class VectorCase:
+    idx: int
+    scs_hz: float
+    start_symbol: int
+    n_alloc_symbols: int
+    beta_dmrs: float
+    smoothing: str
+    cfo_compensate: bool
+    grid_prbs: int
+    layers: List[VectorLayerPattern]
+    expected: List[float] = field(default_factory=list)   # numeric fields between the grid size and the file names
+    files: Dict[str, str] = field(default_factory=dict)   # "input_rg" / "pilots" / "output_ch_est" -> file name
+
+
+def _strip_comments(text: str) -> str:
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def _nested(tokens: List[str], pos: int) -> Tuple[list, int]:
+    """tokens[pos] == '{': returns the nested list up to the matching '}' and the position after it."""
+    out: list = []
+    pos += 1
+    while tokens[pos] != "}":
+        if tokens[pos] == "{":
+            sub, pos = _nested(tokens, pos)
+            out.append(sub)
+        else:
+            if tokens[pos] != ",":
+                out.append(tokens[pos])
+            pos += 1
+    return out, pos + 1
+
+
+def _flat(node) -> List[Any]:
+    return [x for n in node for x in (_flat(n) if isinstance(n, list) else [n])]
+
+
+def _int_list(node) -> Optional[List[int]]:
+    if not isinstance(node, list) or any(isinstance(x, list) or not re.fullmatch(r"[-+]?\d+", x) for x in node):
+        return None
+    return [int(x) for x in node]
+
+
+def _find_patterns(node, grid_prbs: int, n_sym_opts) -> List[VectorLayerPattern]:
+    """Every brace list that directly holds, in this order, a DM-RS symbol mask, one or two grid-wide PRB masks and a
+    12-entry RE pattern (a bare integer among them is the hop symbol; `std::nullopt` and `{}` are skipped)."""
+    found: List[VectorLayerPattern] = []
+    if not isinstance(node, list):
+        return found
+    arrays = [a for a in (_int_list(c) for c in node if isinstance(c, list)) if a and set(a) <= {0, 1}]
+    if (len(arrays) >= 3 and len(arrays[0]) in n_sym_opts and len(arrays[-1]) == 12
+            and all(len(a) == grid_prbs for a in arrays[1:-1])):
+        hop = next((int(c) for c in node if isinstance(c, str) and re.fullmatch(r"\d+", c)), None)
+        masks = [np.array(p, bool) for p in arrays[1:-1][:2] if any(p)] or [np.array(arrays[1], bool)]
+        return [VectorLayerPattern(np.array(arrays[0], bool), masks, hop, np.array(arrays[-1], bool))]
+    for c in node:
+        found += _find_patterns(c, grid_prbs, n_sym_opts)
+    return found
+
+
+def parse_test_data_header(text: str) -> List[VectorCase]:
+    """All test cases of a `port_channel_estimator_test_data.h`, sorted by the index in their file names."""
+    text = _strip_comments(text)
+    start = text.index("{", text.index("=", text.index("port_channel_estimator_test_data")))
+    tokens = _TOKEN.findall(text[start:])
+    top, _ = _nested(tokens, 0)
+    cases: List[VectorCase] = []
+    for n, block in enumerate(b for b in top if isinstance(b, list)):
+        flat = _flat(block)
+
+        def after(prefix: str, count: int) -> List[str]:
+            i = next(k for k, t in enumerate(flat) if isinstance(t, str) and t.startswith(prefix))
+            return [flat[i][len(prefix):]] + flat[i + 1: i + 1 + count]
+
+        scs_khz = int(after("subcarrier_spacing::kHz", 0)[0]) if any(str(t).startswith("subcarrier_spacing::kHz") for t in flat) else 15
+        _, first_sym, n_syms = after("cyclic_prefix::", 2)
+        smoothing, cfo_flag, grid_prbs = after("port_channel_estimator_fd_smoothing_strategy::", 2)
+        i_smooth = next(k for k, t in enumerate(flat) if str(t).startswith("port_channel_estimator_fd_smoothing_strategy::"))
+        betas = [t for t in flat[:i_smooth] if _NUM.match(t) and not re.fullmatch(r"[-+]?\d+", t)]   # the scaling is the only real-valued field of the configuration
+        strings = [t.strip('"') for t in flat if t.startswith('"')]
+        files = {}
+        for s in strings:
+            m = re.search(r"port_channel_estimator_test_(input_rg|pilots|output_ch_est)(\d+)\.dat", s)
+            if m:
+                files[m.group(1)] = s.rsplit("/", 1)[-1]
+                idx = int(m.group(2))
+        if not files:
+            idx = n
+        i_first_str = next((k for k, t in enumerate(flat) if t.startswith('"')), len(flat))
+        expected = [float(t.rstrip("fF")) for t in flat[i_smooth + 3: i_first_str] if _NUM.match(t)]
+        layers = _find_patterns(block, int(grid_prbs), {14, int(n_syms)})
+        if not layers:
+            raise ValueError(f"test case {idx}: no DM-RS pattern block found")
+        cases.append(VectorCase(idx, scs_khz * 1000.0, int(first_sym), int(n_syms), float(betas[-1].rstrip("fF")) if betas else 1.0,
+                                smoothing, cfo_flag == "true", int(grid_prbs), layers, expected, files))
+    return sorted(cases, key=lambda c: c.idx)
+
+
+def normal_cp_ms(scs_hz: float, n_sym: int = 14) -> np.ndarray:
+    """Cyclic-prefix durations the harness feeds the estimator (`validate_all.py:269-283`): 160 / 144 samples at
+    15 kHz scaled to the numerology, on a 2048-point FFT clock, in milliseconds."""
+    scale = 15000.0 / scs_hz
+    samples = np.array([round(160 * scale)] + [round(144 * scale)] * (n_sym - 1), np.float64)
+    return samples / (scs_hz * 2048) * 1e3
+
+
+def case_to_configs(case: VectorCase):
+    """(hop1, hop2, config, n_cdm_columns) in the estimator's terms, following the harness's conventions
+    (`validate_all.py:383-465`): layers that share symbols and PRBs form one hop description whose RE patterns are
+    stacked as CDM columns (duplicates dropped); a hop symbol splits the DM-RS symbols between the two PRB masks;
+    both hops keep the slot-level first symbol / symbol count."""
+    from .config import EstimatorConfig, HopConfig
+
+    first = case.layers[0]
+    cols: List[np.ndarray] = []
+    for lay in case.layers:
+        if not any(np.array_equal(lay.re_pattern, c) for c in cols):
+            cols.append(lay.re_pattern)
+    re_mask = np.stack(cols, axis=1)
+    sym_idx = np.arange(first.dmrs_symbols.size)
+
+    def hop(symbols: np.ndarray, prb_mask: np.ndarray):
+        n = int(prb_mask.sum())
+        return HopConfig(DMRSsymbols=symbols, DMRSREmask=re_mask, PRBstart=int(np.argmax(prb_mask)) if n else 0, nPRBs=n,
+                         maskPRBs=prb_mask, startSymbol=case.start_symbol, nAllocatedSymbols=case.n_alloc_symbols)
+
+    if len(first.prb_masks) == 2:
+        boundary = first.hop_symbol if first.hop_symbol is not None else case.n_alloc_symbols // 2
+        hop1 = hop(first.dmrs_symbols & (sym_idx < boundary), first.prb_masks[0])
+        hop2 = hop(first.dmrs_symbols & (sym_idx >= boundary), first.prb_masks[1])
+    else:
+        hop1 = hop(first.dmrs_symbols, first.prb_masks[0])
+        hop2 = HopConfig(DMRSsymbols=np.zeros(0, bool), DMRSREmask=np.zeros((12, 0), bool), PRBstart=0, nPRBs=0,
+                         maskPRBs=np.zeros(0, bool), startSymbol=0, nAllocatedSymbols=0)
+    config = EstimatorConfig(scs=case.scs_hz, CyclicPrefixDurations=normal_cp_ms(case.scs_hz), Smoothing=case.smoothing,
+                             CFOCompensate=case.cfo_compensate)
+    return hop1, hop2, config, re_mask.shape[1]
+
+
+PILOT_ORDERS = ("sym-re-layer", "layer-sym-re", "re-sym-layer", "sym-layer-re", "layer-re-sym", "re-layer-sym")
+
+
+def run_vector_case(case: VectorCase, data_dir, estimator) -> Dict[str, Any]:
+    """Runs one vector set through `estimator(rx (n_sc, n_sym) c64, pilots (n_re, n_dmrs, L) c64, beta, hop1, hop2,
+    config) -> (ch_est (n_sc, n_sym, L), noise, rsrp, epre, ta, cfo)` and compares at the REs the expected-output
+    file lists (the harness's protocol, `validate_all.py:541-575`, including its search over the pilot file's axis
+    order, which differs between vector sets)."""
+    data_dir = Path(data_dir)
+    name = lambda kind: data_dir / case.files.get(kind, f"port_channel_estimator_test_{kind}{case.idx}.dat")
+    rg, want = read_entries(name("input_rg")), read_entries(name("output_ch_est"))
+    if rg["port"].max(initial=0) > 0:
+        raise ValueError(f"case {case.idx}: more than one Rx port in the input grid")
+    n_sym = max(14, case.n_alloc_symbols, int(rg["symbol"].max(initial=0)) + 1, int(want["symbol"].max(initial=0)) + 1)
+    grid = entries_to_grid(rg, 12 * case.grid_prbs, n_sym)[:, :, 0]
+    hop1, hop2, config, _ = case_to_configs(case)
+    n_dmrs = int(np.asarray(hop1.DMRSsymbols).sum() + np.asarray(hop2.DMRSsymbols).sum())
+    n_re = int(hop1.nPRBs * np.asarray(hop1.DMRSREmask)[:, 0].sum())
+    raw = np.fromfile(name("pilots"), np.complex64)
+    if n_dmrs * n_re == 0 or raw.size % (n_dmrs * n_re):
+        raise ValueError(f"case {case.idx}: pilot file holds {raw.size} values, not a multiple of {n_dmrs} x {n_re}")
+    n_layers = raw.size // (n_dmrs * n_re)
+    best: Dict[str, Any] = {"max": np.inf, "rms": np.inf}
+    seen = set()
+    for order, lperm in itertools.product(PILOT_ORDERS, itertools.permutations(range(n_layers)) if n_layers <= 4 else [tuple(range(n_layers))]):
+        pil = np.ascontiguousarray(read_pilots(name("pilots"), n_dmrs, n_re, n_layers, order)[:, :, list(lperm)])
+        key = pil.tobytes()
+        if key in seen:
+            continue
+        seen.add(key)
+        out = estimator(grid, pil, case.beta_dmrs, hop1, hop2, config)
+        est = np.asarray(out[0])
+        if want["port"].max(initial=0) >= est.shape[2]:
+            raise ValueError(f"case {case.idx}: expected output lists layer {want['port'].max()} but the estimate has {est.shape[2]}")
+        mx, rms = compare_at_entries(est, want)
+        if rms < best["rms"]:
+            best = {"idx": case.idx, "order": order + (":L" + "".join(map(str, lperm)) if n_layers > 1 else ""), "max": mx, "rms": rms, "layers": n_layers,
+                    "scalars": [float(np.asarray(v).reshape(-1)[0]) if np.asarray(v).size else float("nan") for v in out[1:]]}
+    return best
