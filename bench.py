@@ -116,11 +116,19 @@ def main():
     from srsran_ce_pytorch_amd import estimator as E
     from srsran_ce_pytorch_amd.sharding import aggregate_slots_per_second, max_over_ranks
 
+    # CE_BENCH_REHEARSE=1 (dev only, 1-GPU box): all ranks share cuda:0 and rendezvous over gloo, to exercise the
+    # multi-rank control flow where only one GPU exists; its numbers mean nothing
+    rehearse = os.environ.get("CE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     hop1, hop2, cfg = S.numpy_hops(case)
     plan = E.make_plan(hop1, hop2, cfg, case["beta"], 1, case["n_prb_grid"], case["n_sym"], dev, wl.get("interp", "linear"))
@@ -145,7 +153,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms], dev)  # measurement only, not data path
+    elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms], "cpu" if rehearse else dev)  # measurement only, not data path
 
     # sanity: the batch really was estimated (finite outputs, CFO in the generated range)
     assert bool(torch.isfinite(out[1]).all()) and bool(torch.isfinite(out[0][-1, -1].real).all())
@@ -166,13 +174,13 @@ def main():
         "metric": "slots/sec (273-PRB PUSCH, 4 Rx)" if n_ports == 4 else f"slots/sec (273-PRB PUSCH, {n_ports} Rx)",
         "value": value, "unit": "slots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearse else ""),
         "config": {"workload": args.workload, "n_prb": 273, "n_sc": plan.n_sc, "n_sym": plan.n_sym, "dmrs_symbols": [2, 11],
                    "layers": 1, "rx_ports": n_ports, "smoothing": wl["smoothing"], "interp": wl.get("interp", "linear"), "slots_per_gpu": n_slots,
                    "global_slots": world * n_slots, "rx_layout": "[slot][port][sym][sc]", "parallelism": f"slot-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "ce_estimate_kernel<1,1,2>", "kernel_ms": kernel_ms,
+                     "kernel": "ce_estimate_kernel<1,1,2,7>", "kernel_ms": kernel_ms,
                      "alg_bytes_per_slot": bytes_per_slot, "alg_bytes_per_launch": bytes_per_launch},
     }
     if cpu is not None:

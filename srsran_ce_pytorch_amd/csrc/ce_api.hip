@@ -7,10 +7,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <complex>
 #include <string>
 #include <vector>
 
+#include <algorithm>
 #include "ce_plan.h"
 
 struct ce_plan {
@@ -373,8 +375,16 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       for (int c = 0; c < 5; ++c) P.cnn_rcp[c] = 1.0 / (0.25 * c + 1e-12);
     }
   }
+  // Two hops whose fill rectangles share OFDM symbols (the reference harness describes both hops of a hopping
+  // allocation with the slot's whole symbol range, scripts/validation/validate_case4.py:85-103): which hop an
+  // element belongs to then depends on its subcarrier as well, which only the element-wise writer resolves
+  P.sym_overlap = (d->n_hops == 2 && std::max(P.hop[0].sym0, P.hop[1].sym0) < std::min(P.hop[0].sym1, P.hop[1].sym1)) ? 1 : 0;
+  if (P.sym_overlap && d->interp == CE_INTERP_CNN) {
+    delete p;
+    return fail(CE_ERR_UNSUPPORTED, "the in-painting writer needs hops with disjoint symbol ranges");
+  }
   // register path: one layer (two layers' pilots would spill: measured slower than re-reading), every hop
-  // with the same 1 or 2 DM-RS symbols, band fits CE_KPT pilot REs per thread
+  // with the same DM-RS symbol count, band fits CE_KPT pilot REs per thread
   P.reg_kpt = getenv("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : n_re <= 2 * CE_THREADS ? 2 : n_re <= 4 * CE_THREADS ? 4 : CE_KPT);  // env: tuning knob
   P.reg_nd = 0;
   if (L == 1 && n_re <= CE_KPT * CE_THREADS) {

@@ -1187,8 +1187,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
   };
 
   if (CE_ABLATE & 8) {
-  } else if (n_sym == CE_MAX_SYMBOLS) {
-    // Fast writer.  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
+  } else if (n_sym == CE_MAX_SYMBOLS && !lp->sym_overlap) {
+    // Fast writer (hop of an element decided by its symbol alone).  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
     // each of ACTIVE (a multiple of 252) threads owns ONE (symbol, layer) float4 phase for the whole item:
     // its two rotation phasors and hop/layer selection live in registers, and a workgroup iteration
     // stores ACTIVE*16 contiguous bytes.  The interpolated, un-rotated response H[hop][layer][sc] is staged in the LDS
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
       }
     }
   } else {
-    // generic writer (any n_sym): decode (subcarrier, symbol, layer) per element
+    // generic writer (any n_sym, hops that share symbols): decode (subcarrier, symbol, layer) per element
     auto elem = [&](int sc, int rem) -> float2 {
       const int sym = rem / L, l = rem - sym * L;
       float2 val = make_float2(0.f, 0.f);

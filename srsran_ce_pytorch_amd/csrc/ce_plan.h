@@ -47,7 +47,7 @@ struct CeDevPlan {
   int32_t n_sc, n_sym, n_layers, n_cdm, n_hops, smoothing, cfo_comp, interp;
   int32_t n_re, n_re_pad, n_pils, rc_len, ext_len, filt_lpp;
   int32_t cfo_estimated, reg_nd;      // reg_nd: DM-RS symbols per hop held in registers (0 = re-read path)
-  int32_t reg_kpt, pad3;              // pilot REs per thread on the register path: smallest of 1, 2, 4, CE_KPT covering n_re
+  int32_t reg_kpt, sym_overlap;              // pilot REs per thread on the register path: smallest of 1, 2, 4, CE_KPT covering n_re; sym_overlap: the hops' fill rectangles share symbols
   int32_t scratch_bytes, wr_ch_log2;  // LDS scratch size; log2 of the writer's subcarrier chunk
   float beta_f;
   double beta, scs, denom_cdm, n_pilots, noise_den;

@@ -11,7 +11,7 @@ Storage: the reference only reads DM-RS symbols of the grid, so fixtures keep ju
 columns (``grid_cols``); every other RE of the input grid is zero, both when the reference was
 run and when a test rebuilds the grid (``load_fixture`` in tests/conftest.py).
 
-Usage:  python tools/make_golden.py
+Usage:  python tools/make_golden.py [fixture names ...]
 """
 from __future__ import annotations
 
@@ -59,6 +59,10 @@ def golden_cases():
         (CS("partial_symbols_nocfo", 52, [H([3, 10], 4, 8, 2, 10)], seed=13, cfo_compensate=False), "T", 1),
         (CS("dmrs3_scs15", 25, [H([2, 7, 11], 0, 25)], scs=15e3, seed=18), "T", 1),
         (CS("layers4_273", 273, [H([2, 11], 0, 273, re_masks=BOTH)], n_layers=4, seed=14), "T", 1),
+        # hops whose fill rectangles share symbols: the harness's own two-hop convention (validate_case4.py:85-103: both
+        # hops carry the slot's symbol range) and a partial overlap in symbols AND PRBs (hop 2 overwrites, T:872-896)
+        (CS("case4like_fullslot_hops", 52, [H([0, 4], 3, 3, 0, 14), H([8, 12], 28, 3, 0, 14)], scs=15e3, seed=30), "T", 2),
+        (CS("hops_partial_overlap_L2", 52, [H([1, 4], 5, 8, 0, 10), H([8, 12], 9, 8, 6, 8)], n_layers=2, seed=31), "T", 1),
         (CS("cnn_3prb", 52, [H([2, 11], 7, 3)], seed=20), "C", 2),
         (CS("cnn_type2_3prb", 52, [H([2, 11], 7, 3, re_masks=[S.TYPE2_CDM0])], seed=21), "C", 2),
         (CS("cnn_type2_2hop", 52, [H([2], 3, 3, 0, 7, [S.TYPE2_CDM0]), H([9], 28, 3, 7, 7, [S.TYPE2_CDM0])], seed=23), "C", 1),
@@ -91,8 +95,11 @@ def run_ref(mod, b, grid, case):
 def main():
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
-    manifest = {}
+    only = set(sys.argv[1:])          # optional: regenerate just the named fixtures (MANIFEST.json is updated, not rewritten)
+    manifest = json.loads((out_dir / "MANIFEST.json").read_text()) if only and (out_dir / "MANIFEST.json").exists() else {}
     for case, variant, n_items in golden_cases():
+        if only and case["name"] not in only:
+            continue
         b = S.build_case(case, n_items)
         cols = sorted({s for h in case["hops"] for s in h["dmrs_symbols"]})
         grids = np.zeros_like(b.grids)
