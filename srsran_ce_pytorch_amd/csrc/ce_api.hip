@@ -215,7 +215,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       if (dpp == 0) { delete p; return fail(CE_ERR_INVALID, "hop %d: DMRSREmask column %d is empty", h, c); }
       H.dpp[c] = dpp;
       H.mask12 |= m << (16 * c);
-      H.div_magic[c] = (uint32_t)(0x100000000ull / (unsigned)dpp) + 1u;
+      H.div_magic[c] = dpp > 1 ? (uint32_t)(0x100000000ull / (unsigned)dpp) + 1u : 0u;  // dpp == 1: k / dpp == k (the magic would need 33 bits)
       {
         uint64_t pos = 0, ord = 0;
         int j = 0;
@@ -300,7 +300,8 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     P.rc_len = (int)rc.size();
     for (size_t i = 0; i < rc.size(); ++i) P.rc[i] = rc[i];
     P.n_pils = n_active > 1 ? ((int)rc.size() / 2 < 12 ? (int)rc.size() / 2 : 12) : dpp0;  // T:644-647
-    if (P.n_pils > n_re || P.n_pils < 1) { delete p; return fail(CE_ERR_UNSUPPORTED, "n_pils=%d vs n_re=%d", P.n_pils, n_re); }
+    // n_pils == 0 (a one-tap filter: stride 12 over two PRBs) is valid: no virtual pilots, identity FIR (T:649-664)
+    if (P.n_pils > n_re) { delete p; return fail(CE_ERR_UNSUPPORTED, "n_pils=%d vs n_re=%d", P.n_pils, n_re); }
     P.ext_len = n_re + 2 * P.n_pils;
     for (size_t i = 0; i < rc.size(); ++i) P.rcz[i + CE_CONV_C - 1] = rc[i];
     {
@@ -308,7 +309,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       double sxx = 0.0;
       for (int i = 0; i < P.n_pils; ++i) sxx += (double)i * (double)i;
       P.vp_mx = (n - 1.0) / 2.0;
-      P.vp_inv_n = 1.0 / n;
+      P.vp_inv_n = P.n_pils > 0 ? 1.0 / n : 0.0;
       P.vp_inv_denom = P.n_pils > 1 ? 1.0 / (sxx - n * P.vp_mx * P.vp_mx) : 0.0;
     }
     // windowed FIR: band fits 9 outputs x 192 threads, both edge zones (len(rc)/2 outputs each) are disjoint

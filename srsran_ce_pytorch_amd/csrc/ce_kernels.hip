@@ -278,7 +278,7 @@ __device__ __forceinline__ int64_t item_of(int64_t b, int n_ports, int64_t n_ite
 // subcarrier of pilot k of CDM group c: computed for a contiguous allocation, looked up otherwise (T:572-576)
 __device__ __forceinline__ int pilot_sc(const CeDevHop& hp, const uint16_t* __restrict__ re_idx, int c, int k) {
   if (hp.contig) {
-    const int q = (int)__umulhi((unsigned)k, hp.div_magic[c]);
+    const int q = hp.dpp[c] == 1 ? k : (int)__umulhi((unsigned)k, hp.div_magic[c]);
     const int j = k - q * hp.dpp[c];
     return 12 * (hp.prb_start + q) + (int)((hp.pos_packed[c] >> (4 * j)) & 15u);
   }

@@ -35,7 +35,7 @@ struct CeDevHop {
   int32_t ta_inv_off;                 // offset of this hop's subcarrier -> pilot-ordinal table (0xFFFF = no pilot)
   int32_t contig;                     // maskPRBs == [PRBstart, PRBstart+nPRBs): pilot positions are computed, not looked up
   int32_t prb_start, n_prbs;
-  uint32_t div_magic[CE_MAX_CDM];     // floor(2^32 / dpp) + 1: k / dpp == umulhi(k, magic) for k < 2^16
+  uint32_t div_magic[CE_MAX_CDM];     // floor(2^32 / dpp) + 1: k / dpp == umulhi(k, magic) for k < 2^16 (dpp >= 2; unused for dpp == 1)
   uint64_t pos_packed[CE_MAX_CDM];    // 4 bits per pilot j of a PRB: its RE position
   uint64_t ord_packed;                // last CDM group: 4 bits per RE r: pilot ordinal inside the PRB, 15 = not a pilot
   uint64_t ta_res_packed;             // 4 bits per entry of ta_res
