@@ -212,3 +212,23 @@ def test_unusual_re_masks(mask, smoothing, n_prbs):
         if mask == "single" and n_prbs == 1:
             got[3] = want[3]
         check_outputs(ch[it], got, ref[0], want, TOL_CH, TOL_SC, f"{mask}/{smoothing}/{n_prbs}[{it}]")
+
+
+@pytest.mark.parametrize("n_slots,n_ports", [(1, 1), (3, 2), (9, 3), (17, 4), (8, 5), (25, 1), (16, 2), (7, 8)])
+def test_batch_placement_is_a_permutation(n_slots, n_ports):
+    """The workgroup -> (slot, port) map deals the ports of a slot 8 workgroups apart (XCD-aware placement,
+    `item_of`) and falls back to the identity on the ragged tail: for any batch shape every item must be
+    estimated exactly once and from its own slot's pilots -- batch results equal the slot-by-slot results bit
+    for bit (same kernel, same arithmetic)."""
+    dev = _dev()
+    case = S.case_spec("perm", 25, [S.hop_spec([2, 11], 3, 20)], seed=77)
+    h1, h2, cfg = S.numpy_hops(case)
+    rx, pil = S.torch_inputs(case, n_slots, n_ports, dev, seed=5)
+    out = E.estimate(rx, pil, case["beta"], h1, h2, cfg)
+    for s in range(n_slots):
+        one = E.estimate(rx[s:s + 1], pil[s:s + 1], case["beta"], h1, h2, cfg)
+        for a, b in zip(out, one):
+            assert torch.equal(a[s:s + 1], b), f"slot {s} of a {n_slots}x{n_ports} batch"
+    # distinct slots really differ (otherwise the comparison above proves nothing)
+    if n_slots > 1:
+        assert not torch.equal(out[0][0], out[0][1])

@@ -50,7 +50,15 @@ def draw(rng, max_grid):
     if n_hops == 2 and rng.random() < 0.5:          # same DM-RS count in both hops (register path)
         k = min(len(hops[0]["dmrs_symbols"]), len(hops[1]["dmrs_symbols"]))
         hops[0]["dmrs_symbols"], hops[1]["dmrs_symbols"] = hops[0]["dmrs_symbols"][:k], hops[1]["dmrs_symbols"][:k]
-    case = S.case_spec("fuzz", grid, hops, n_layers=layers, smoothing=str(rng.choice(["none", "mean", "filter"])),
+    n_sym = 14 if (rng.random() < 0.9 or interp == "cnn") else 12          # 12: generic writer; CFO ramp impossible (T:928)
+    if n_sym == 12:
+        for h in hops:
+            h["dmrs_symbols"] = sorted({min(s, 11) for s in h["dmrs_symbols"]})
+            h["start_symbol"], h["n_alloc"] = min(h["start_symbol"], 11), min(h["n_alloc"], 12 - min(h["start_symbol"], 11))
+        if n_hops == 2 and set(hops[0]["dmrs_symbols"]) & set(hops[1]["dmrs_symbols"]):
+            n_sym = 14
+    smoothing = str(rng.choice(["none", "mean", "filter", "filter", "mmse"])) if interp == "linear" else str(rng.choice(["none", "mean", "filter"]))
+    case = S.case_spec("fuzz", grid, hops, n_layers=layers, smoothing=smoothing, n_sym=n_sym,
                        cfo_compensate=bool(rng.random() < 0.8), scs=float(rng.choice([15e3, 30e3, 60e3])),
                        seed=int(rng.integers(1 << 30)), cfo_hz=float(rng.uniform(-400, 400)), delay_ns=float(rng.uniform(0, 400)))
     return case, interp
@@ -74,6 +82,8 @@ def main():
             continue
         if interp == "cnn":
             b.config.CNNSmoothingAlpha = float(rng.choice([0.0, 0.4]))
+        if case["smoothing"] == "mmse":              # extension: checked against its own oracle
+            b.config.MMSEDelaySpread, b.config.MMSENoiseToSignal = float(rng.choice([0.3e-6, 1.2e-6])), float(rng.choice([0.01, 0.1]))
         scattered = rng.random() < 0.15              # maskPRBs not the PRBstart..+nPRBs run: table-lookup paths (pilot positions, TA map)
         if scattered:
             for hop in (b.hop1, b.hop2):
@@ -88,7 +98,7 @@ def main():
         try:
             for it in range(2):
                 want.append(O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=interp))
-        except (ValueError, AssertionError) as e:
+        except (ValueError, AssertionError, IndexError) as e:   # IndexError: a DM-RS mask shorter than the 14 symbol start times (T:440-447)
             werr = e
         try:
             g = torch.as_tensor(b.grids, device=dev)[None]
@@ -101,7 +111,9 @@ def main():
             print(f"[{i}] UNSUPPORTED {e} :: {tag}", flush=True)
             continue
         except (ValueError, AssertionError) as e:
-            if werr is None or type(e) is not type(werr):
+            if isinstance(werr, IndexError) and isinstance(e, ValueError):
+                raised += 1                          # the reference crashes on the shape; the boundary reports it as invalid
+            elif werr is None or type(e) is not type(werr):
                 bad += 1
                 print(f"[{i}] HIP raised {type(e).__name__}: {e}; oracle: {werr!r} :: {tag}", flush=True)
             else:
@@ -117,12 +129,12 @@ def main():
             ref = want[it]
             got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], np.nan if sc[4] is None else sc[4][it]]
             rs = [ref[1], ref[2], ref[3], ref[4], np.nan if ref[5] is None else ref[5]]
-            for j in range(5):                       # both non-finite the same way (1 pilot: noise = x / 0) counts as equal
-                if not np.isfinite(rs[j]) and (np.isnan(rs[j]) == np.isnan(got[j])) and (np.isnan(rs[j]) or rs[j] == got[j]):
+            for j in range(5):                       # both non-finite (1 pilot: noise = residual / 0 is inf or nan by rounding) counts as equal
+                if not np.isfinite(rs[j]) and not np.isfinite(got[j]) and (j != 4 or np.isnan(rs[j]) == np.isnan(got[j])):
                     rs[j] = got[j] = 0.0 if j != 4 else np.nan
             if b.pilots.shape[0] == 1:
                 got[3] = rs[3]                       # a single pilot: every TA bin ties, the arg-max is rounding noise
-            elif b.pilots.shape[0] <= 12 and got[3] != rs[3] and abs(got[3] - rs[3]) <= 1.001 / 4096 / case["scs"]:
+            elif b.pilots.shape[0] <= 12 and 0.5 / 4096 / case["scs"] < abs(got[3] - rs[3]) <= 1.001 / 4096 / case["scs"]:
                 near_ties += 1                       # <= 12 pilots: the IFFT peak is flat to ~1e-7, neighbouring bins swap on rounding
                 got[3] = rs[3]
             if np.isfinite(rs[4]) and abs(got[4] - rs[4]) <= 5e-8 * case["scs"]:
