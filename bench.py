@@ -12,6 +12,8 @@ Workloads (BASELINE.json configs):
                         This is the configuration the metric ("273-PRB PUSCH, 4 Rx") is quoted on.
   pusch273_1rx_none     configs[1]: LS + linear interpolation, 273 PRB / 1 Rx / 1024 slots.
   pusch273_4rx_mmse     EXTENSION (parity unpinned): block LMMSE/Wiener smoothing on f32 MFMA instead of the RC FIR.
+  pusch273_4rx_denoise  EXTENSION (parity unpinned): estimation + the fp16 Conv2d denoiser of include/ce_denoise.h on MFMA
+                        (random weights); its roofline object is MFMA-bound and describes the denoiser kernel.
   pusch273_4rx_cnn      configs[4]: the ce_dl_cnn.py variant (fixed-weight 1-D in-painting instead of linear
                         interpolation; the reference has no Conv2d / fp16 / learned weights).
 
@@ -41,46 +43,61 @@ WORKLOADS = {
     # configs[2] as BASELINE.json words it ("MMSE Wiener filter on"): an EXTENSION -- the reference has no such mode
     # (SURVEY 0.4), its only oracle is the build's own numpy restatement => parity unpinned, reported separately
     "pusch273_4rx_mmse": dict(smoothing="mmse", ports=4, slots=8192),
+    # configs[4] as BASELINE.json words it ("Conv2d over RE grid, fp16, MFMA path"): an EXTENSION with random weights --
+    # the reference has no learned denoiser; estimation (filter) + the 3-layer Conv2d post-processor per step
+    "pusch273_4rx_denoise": dict(smoothing="filter", ports=4, slots=8192, denoise=True),
 }
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 MFMA (same guide; 2:1-sparsity figures are never the yardstick)
+DENOISE_FLOP_PER_PIXEL = 2 * 9 * (2 * 16 + 16 * 16 + 16 * 2)   # useful MACs x 2 of the three 3x3 layers
 
 
 def _cpu_worker(args):
     """Oracle (CPU port of the reference algorithm) on one slot's ports, repeated; returns items done."""
-    case, n_ports, reps, seed, interp = args
+    case, n_ports, reps, seed, interp, denoise = args
     sys.path.insert(0, str(ROOT / "oracle"))
     import ce_oracle as O
     from srsran_ce_pytorch_amd import synth as S
 
     b = S.build_case(dict(case, seed=seed), n_ports)
+    if denoise:                                                         # extension workload: its own numpy restatement
+        import ce_denoise_oracle as DO
+        from srsran_ce_pytorch_amd.denoiser import random_weights
+        weights = random_weights(0)
+
+    def one(r):
+        out = O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=interp)
+        if denoise:
+            DO.denoise(out[0], weights)
+
     for _ in range(2):                                                  # untimed warm-up (page faults, caches)
         for r in range(n_ports):
-            O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=interp)
+            one(r)
     t0 = time.perf_counter()
     for _ in range(reps):
         for r in range(n_ports):
-            O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=interp)
+            one(r)
     return reps * n_ports, time.perf_counter() - t0
 
 
-def cpu_baseline(case, n_ports, target_core_seconds=20.0, interp="linear"):
+def cpu_baseline(case, n_ports, target_core_seconds=20.0, interp="linear", denoise=False):
     """Bounded sample of the same workload on the host cores (fork happens BEFORE any GPU init)."""
     import multiprocessing as mp
 
     cores = min(16, len(os.sched_getaffinity(0)))
-    n1, t1 = _cpu_worker((case, n_ports, 3, 999, interp))         # per-item estimate on one core
+    n1, t1 = _cpu_worker((case, n_ports, 3, 999, interp, denoise))         # per-item estimate on one core
     per_item = t1 / n1
     reps = max(1, int(target_core_seconds / cores / (per_item * n_ports)))
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(case, n_ports, reps, 1000 + i, interp) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(case, n_ports, reps, 1000 + i, interp, denoise) for i in range(cores)])
     wall = time.perf_counter() - t0
     items = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
     slots = items / n_ports
     return dict(value=slots / busy, unit="slots/s", cores=cores, kind="port",
                 sample=f"{int(slots)} slots x {n_ports} ports of the same 273-PRB workload through oracle/ce_oracle.py "
-                       f"(numpy port of {'ce_dl_cnn' if interp == 'cnn' else 'ce_rule_tensorized'}), {cores} worker processes, {busy:.1f} s busy / {wall:.1f} s wall; "
+                       f"(numpy port of {'ce_dl_cnn' if interp == 'cnn' else 'ce_rule_tensorized'}{' + oracle/ce_denoise_oracle.py' if denoise else ''}), {cores} worker processes, {busy:.1f} s busy / {wall:.1f} s wall; "
                        f"{per_item * 1e3:.2f} ms per slot-port on one core")
 
 
@@ -109,7 +126,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(case, n_ports, interp=wl.get("interp", "linear"))   # before any GPU initialisation (forks)
+        cpu = cpu_baseline(case, n_ports, interp=wl.get("interp", "linear"), denoise=bool(wl.get("denoise")))   # before any GPU initialisation (forks)
 
     import torch
     import torch.distributed as dist
@@ -134,7 +151,16 @@ def main():
     plan = E.make_plan(hop1, hop2, cfg, case["beta"], 1, case["n_prb_grid"], case["n_sym"], dev, wl.get("interp", "linear"))
     rx, pilots = S.torch_inputs(case, n_slots, n_ports, dev, seed=1234 + rank)
     out = E.estimate_with_plan(plan, rx, pilots)                    # allocates the outputs once
+    denoiser = None
+    if wl.get("denoise"):
+        from srsran_ce_pytorch_amd.denoiser import Denoiser, random_weights
+        denoiser = Denoiser(random_weights(0), dev)
     torch.cuda.synchronize()
+
+    def step():
+        E.estimate_with_plan(plan, rx, pilots, out)
+        if denoiser is not None:
+            denoiser(out[0])
 
     def barrier():
         if world > 1:
@@ -142,13 +168,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        E.estimate_with_plan(plan, rx, pilots, out)
+        step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                                                    # same stream the kernel is launched on
     for _ in range(args.steps):
-        E.estimate_with_plan(plan, rx, pilots, out)
+        step()
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -183,6 +209,23 @@ def main():
                      "kernel": "ce_estimate_kernel<1,1,2,7>", "kernel_ms": kernel_ms,
                      "alg_bytes_per_slot": bytes_per_slot, "alg_bytes_per_launch": bytes_per_launch},
     }
+    if denoiser is not None:
+        # dominant kernel of this workload: the denoiser; timed on its own (same stream, same resident batch)
+        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d0.record()
+        for _ in range(args.steps):
+            denoiser(out[0])
+        d1.record()
+        torch.cuda.synchronize()
+        dn_ms = max_over_ranks([d0.elapsed_time(d1) / args.steps], "cpu" if rehearse else dev)[0]
+        flops = n_slots * n_ports * plan.n_sc * plan.n_sym * DENOISE_FLOP_PER_PIXEL
+        ach = flops / (dn_ms * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_PEAK_TFLOPS,
+                            "traffic": None, "kernel": "ce_denoise_kernel", "kernel_ms": dn_ms, "alg_flop_per_launch": flops,
+                            "note": "useful flops of the three 3x3 layers (2->16->16->2); the kernel issues 2.3x that on MFMA (K and N padding)",
+                            "estimation_kernel_ms": kernel_ms - dn_ms}
+        line["dtype"] = "f32 estimation + f16 Conv2d (f32 accumulate)"
+        line["config"]["extension"] = "Conv2d denoiser, random weights, parity unpinned"
     if cpu is not None:
         line["cpu_baseline"] = cpu
     if rank == 0:

@@ -15,7 +15,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = Path(os.environ.get("CE_HIP_LIB", CSRC / "libce_hip.so"))   # override: diagnostic builds (tools/)
-SOURCES = ["ce_api.hip", "ce_kernels.hip"]
+SOURCES = ["ce_api.hip", "ce_kernels.hip", "ce_denoise.hip"]
 
 CE_ABI_VERSION = 2
 CE_MAX_CDM, CE_MAX_HOPS, CE_MAX_SYMBOLS = 2, 2, 14
@@ -59,17 +59,39 @@ class PlanHostView(C.Structure):
 
 EXPORTS = ["ce_plan_create", "ce_plan_destroy", "ce_plan_get_info", "ce_plan_derive_host", "ce_estimate_batch",
            "ce_time_batch", "ce_last_error", "ce_abi_version"]
+EXPORTS_DENOISE = ["ce_denoiser_create", "ce_denoiser_destroy", "ce_denoise_batch"]   # include/ce_denoise.h (extension)
+
+
+# per-source compiler flags: the denoiser's MFMA results feed vector instructions straight away, so keep them in
+# VGPRs (the default AGPR form costs four v_accvgpr_read per 16x16 tile in a kernel bound by vector-instruction issue)
+EXTRA_FLAGS = {"ce_denoise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -> csrc/libce_hip.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> csrc/libce_hip.so (cross-compiles without a GPU): one object per source
+    (compiled concurrently, each with its own flags), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / "ce_plan.h", INCLUDE / "ce_hip.h"]
+    deps = srcs + [CSRC / "ce_plan.h", INCLUDE / "ce_hip.h", INCLUDE / "ce_denoise.h", Path(__file__)]
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
-           "-o", str(LIB_PATH)] + [str(s) for s in srcs]
+    objdir = CSRC / ".build"
+    objdir.mkdir(exist_ok=True)
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+    def compile_one(src: Path) -> Path:
+        obj = objdir / (src.stem + ".o")
+        cmd = common + EXTRA_FLAGS.get(src.name, []) + ["-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(o) for o in objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -106,6 +128,13 @@ def load() -> C.CDLL:
     lib.ce_last_error.restype = C.c_char_p
     lib.ce_abi_version.argtypes = []
     lib.ce_abi_version.restype = C.c_int
+    fp = C.POINTER(C.c_float)
+    lib.ce_denoiser_create.argtypes = [C.c_int32, fp, fp, fp, fp, fp, fp, C.POINTER(vp)]
+    lib.ce_denoiser_create.restype = C.c_int
+    lib.ce_denoiser_destroy.argtypes = [vp]
+    lib.ce_denoiser_destroy.restype = None
+    lib.ce_denoise_batch.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.ce_denoise_batch.restype = C.c_int
     if lib.ce_abi_version() != CE_ABI_VERSION:
         raise RuntimeError(f"libce_hip.so ABI {lib.ce_abi_version()} != binding {CE_ABI_VERSION}; rebuild")
     _lib = lib

@@ -28,9 +28,9 @@ struct ce_plan {
   std::vector<float> mmse_w;  // extension: Re | Im of W[m][k], CE_MMSE_BLOCK^2 each
 };
 
-namespace {
-
 thread_local std::string g_err;
+
+namespace {
 
 int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -41,6 +41,20 @@ int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+
+}  // namespace
+
+int ce_fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+namespace {
 
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \

@@ -1,0 +1,317 @@
+// EXTENSION (no reference counterpart, see include/ce_denoise.h): 3-layer residual Conv2d denoiser over the
+// (subcarrier, symbol) plane of the channel estimate, fp16 operands on v_mfma_f32_16x16x32_f16.
+//
+// One 256-thread workgroup owns one (item, layer) plane and walks it in strips of DN_T subcarriers; the three layers of a
+// strip run back to back out of LDS (activations [row][16 columns][16 channels] fp16, columns 0 and 15 = the zero padding
+// of symbols -1 and 14), so HBM sees the plane once in and once out.  Implicit GEMM, D = W X:
+//   A = weights   [c_out 16][K 32]   lane l: row l&15, k = 8(l>>4)+j   (registers, packed on the host)
+//   B = activations [K 32][16 columns of one subcarrier row], K = 2 taps x 16 input channels:
+//       lane l: column l&15, tap 2m + (l>>5), channels 8((l>>4)&1) .. +7  -> one ds_read_b128 per MFMA
+//   D lane l: column l&15, c_out 4(l>>4)+i -> one ds_write_b64 per tile.
+// 9 taps = 4.5 K-steps -> 5 MFMAs per (row, layer); tap 9 has zero weights and re-reads tap 8's address.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "ce_denoise.h"
+#include "ce_plan.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ce_denoiser {
+  int device = 0;
+  half8* wfrag = nullptr;  // [11][64]: layer 1 (1 K-step), layer 2 (5), layer 3 (5)
+  float* bias = nullptr;   // [3][16]
+};
+
+#ifndef DN_ABLATE
+#define DN_ABLATE 0   // timing experiments only: 1 no global stores, 2 no global loads, 4 skip layer 1, 8 skip layer 2, 16 skip layer 3, 32 no barriers
+#endif
+
+namespace {
+
+constexpr int DN_T = 32;                  // output subcarriers per strip
+constexpr int DN_NT = 256, DN_COLS = 16, DN_C = CE_DN_CHANNELS;
+constexpr int X0_PIX = (DN_T + 6) * DN_COLS + 2;  // + one pad pixel in front and behind
+constexpr int X1_PIX = (DN_T + 4) * DN_COLS + 2;
+constexpr int X2_PIX = (DN_T + 2) * DN_COLS + 2;
+
+__device__ __forceinline__ int tap_off(int tap) {  // pixel offset of tap t = 3 (dy+1) + (dx+1) in the [row][16] image
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  return (ky - 1) * DN_COLS + (kx - 1);
+}
+
+constexpr int ROW_BYTES16 = DN_COLS * DN_C * 2;  // one image row of a 16-channel layer: 512 B
+constexpr int ROW_BYTES0 = DN_COLS * 4;          // one image row of x0 (fp16 re, im): 64 B
+
+// fp16 + ReLU of one D fragment (c_out 4g .. 4g+3 of one pixel): round first, then a packed max -- rounding to
+// nearest is monotonic and keeps the sign, so this equals fp16(ReLU(x)); 2 converts + 2 packed max instead of 8 + 2
+typedef _Float16 half2x __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half4 relu_h4(f32x4 acc) {
+  half2x lo = half2x{(_Float16)acc[0], (_Float16)acc[1]}, hi = half2x{(_Float16)acc[2], (_Float16)acc[3]};
+  const half2x z = half2x{0, 0};
+  lo = __builtin_elementwise_max(lo, z);
+  hi = __builtin_elementwise_max(hi, z);
+  return half4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// The kernel is bound by vector-instruction issue, not by the MFMAs, unless the per-tile bookkeeping is scalar or
+// constant: every LDS address below is a per-lane constant plus a compile-time tile offset (the tile loops are fully
+// unrolled: tile k of a wave is image row wave + 4k), row validity is wave-uniform (scalar branch), the padding columns
+// are never written (they stay zero from the initial clear), and global offsets are 32-bit from a per-strip scalar base.
+__global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ ch, const half8* __restrict__ wfrag,
+                                                            const float* __restrict__ bias, int n_sc, int L) {
+  __shared__ __attribute__((aligned(16))) half2v x0[2][X0_PIX];
+  __shared__ __attribute__((aligned(16))) _Float16 x1[X1_PIX * DN_C];
+  __shared__ __attribute__((aligned(16))) _Float16 x2[X2_PIX * DN_C];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int64_t plane = blockIdx.x;
+  const int64_t item = plane / L;
+  const int l = (int)(plane - item * L);
+  float2* base = ch + item * (int64_t)n_sc * CE_DN_SYMBOLS * L + l;
+
+  half8 w1 = wfrag[lane], w2[5], w3[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    w2[m] = wfrag[(1 + m) * 64 + lane];
+    w3[m] = wfrag[(6 + m) * 64 + lane];
+  }
+  f32x4 b1, b2, b3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b1[i] = bias[4 * g + i];
+    b2[i] = bias[16 + 4 * g + i];
+    b3[i] = bias[32 + 4 * g + i];
+  }
+  // pad pixels and padding columns are read but never written: zero the images once
+  for (int i = tid; i < 2 * X0_PIX; i += DN_NT) (&x0[0][0])[i] = half2v{0, 0};
+  for (int i = tid; i < X1_PIX * DN_C; i += DN_NT) x1[i] = 0;
+  for (int i = tid; i < X2_PIX * DN_C; i += DN_NT) x2[i] = 0;
+
+  // ---- per-lane constants
+  const bool col_ok = n >= 1 && n <= CE_DN_SYMBOLS;
+  // layer 1 reads: taps 4g .. 4g+3 of x0 at image row wave + 1 (+ 4k rows per tile)
+  int rd0[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tap = 4 * g + q;
+    rd0[q] = (1 + (wave + 1) * DN_COLS + n + tap_off(tap < 9 ? tap : 4)) * 4;
+  }
+  // 16-channel layers: K-step m reads tap 2m + (g >> 1), channels 8 (g & 1) .. +7, at image row wave + 1
+  // The two 16-byte channel halves of pixel p are stored swapped when bit 2 of p is set: the b128 fragment reads stay
+  // conflict-free and the D-fragment ds_write_b64 (16 lanes, 32-byte stride) drops from a 4-way to a 2-way bank conflict.
+  // Tiles advance by 64 pixels, so the swap is a per-lane constant.
+  int rd[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int tap = 2 * m + (g >> 1);
+    const int pix = 1 + (wave + 1) * DN_COLS + n + tap_off(tap < 9 ? tap : 8);
+    rd[m] = pix * (DN_C * 2) + (((g & 1) ^ ((pix >> 2) & 1)) * 16);
+  }
+  const int wpix = 1 + wave * DN_COLS + n;  // D fragment of image row wave: channels 4g .. 4g+3
+  const int wr = wpix * (DN_C * 2) + ((((g >> 1) & 1) ^ ((wpix >> 2) & 1)) * 16) + (g & 1) * 8;
+  // global offsets (complex elements) from the strip's first grid row r0
+  constexpr int ST_N = ((DN_T + 6) * DN_COLS + DN_NT - 1) / DN_NT;
+  int st_off[ST_N], st_row[ST_N];
+  bool st_ok[ST_N];
+#pragma unroll
+  for (int k = 0; k < ST_N; ++k) {
+    const int i = tid + k * DN_NT, sym = (i & 15) - 1;
+    st_row[k] = (i >> 4) - 3;
+    st_ok[k] = i < (DN_T + 6) * DN_COLS && sym >= 0 && sym < CE_DN_SYMBOLS;
+    st_off[k] = (st_row[k] * CE_DN_SYMBOLS + sym) * L;
+  }
+  const int h_off = (wave * CE_DN_SYMBOLS + (n - 1)) * L;  // residual / output of image row wave (+ 4k rows per tile)
+  const bool h_lane = g == 0 && col_ok;
+
+  float2 st[ST_N];
+  auto stage_load = [&](int r0) {  // rows r0-3 .. r0+T+2 -> registers (zeros outside the grid)
+    const float2* sb = base + (int64_t)r0 * CE_DN_SYMBOLS * L;
+#pragma unroll
+    for (int k = 0; k < ST_N; ++k) {
+      st[k] = make_float2(0.f, 0.f);
+      if (!(DN_ABLATE & 2) && st_ok[k] && (unsigned)(r0 + st_row[k]) < (unsigned)n_sc) st[k] = sb[st_off[k]];
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < ST_N; ++k) {
+      const int i = tid + k * DN_NT;
+      if (i < (DN_T + 6) * DN_COLS) x0[buf][1 + i] = half2v{(_Float16)st[k].x, (_Float16)st[k].y};
+    }
+  };
+  stage_load(0);
+  __syncthreads();  // the clear above
+  stage_store(0);
+  __syncthreads();
+  const int n_strips = (n_sc + DN_T - 1) / DN_T;
+#pragma unroll 1
+  for (int s = 0; s < n_strips; ++s) {
+    const int r0 = s * DN_T, buf = s & 1;
+    float2* sb = base + (int64_t)r0 * CE_DN_SYMBOLS * L;
+    // The next strip's input rows overlap this strip's output rows: request them (and this strip's float32 residuals)
+    // now, before layer 3 overwrites them; they are consumed after layer 1 / in layer 3.
+    if (s + 1 < n_strips) stage_load(r0 + DN_T);
+    float2 hres[DN_T / 4];
+#pragma unroll
+    for (int k = 0; k < DN_T / 4; ++k) {
+      hres[k] = make_float2(0.f, 0.f);
+      if (!(DN_ABLATE & 2) && r0 + wave + 4 * k < n_sc && h_lane) hres[k] = sb[h_off + 4 * k * CE_DN_SYMBOLS * L];
+    }
+    // ---- layer 1: x0 -> x1 image rows 0 .. T+3 (image row t <-> grid row r0-2+t); K = (tap, re | im)
+    {
+      const char* xin = reinterpret_cast<const char*>(&x0[buf][0]);
+      char* xout = reinterpret_cast<char*>(x1);
+#pragma unroll
+      for (int k = 0; k < (DN_T + 4) / 4; ++k) {
+        half8 b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // taps >= 9 (K padding) have zero weights: whatever finite pixel their lanes read does not matter
+          const half2v v = *reinterpret_cast<const half2v*>(xin + rd0[q] + k * 4 * ROW_BYTES0);
+          b[2 * q] = v[0];
+          b[2 * q + 1] = v[1];
+        }
+        const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b, b1, 0, 0, 0);
+        const int row = r0 - 2 + wave + 4 * k;  // wave-uniform: outside the grid the next layer must see zero padding
+        half4 o = half4{0, 0, 0, 0};
+        if (row >= 0 && row < n_sc) o = relu_h4(acc);
+        if (col_ok) *reinterpret_cast<half4*>(xout + wr + k * 4 * ROW_BYTES16) = o;
+      }
+    }
+    __syncthreads();
+    if (s + 1 < n_strips) stage_store(buf ^ 1);  // x0[buf ^ 1] was last read by layer 1 of the previous strip
+    // ---- layer 2: x1 -> x2 image rows 0 .. T+1 (image row t <-> grid row r0-1+t).  The five B fragments of tile k+1
+    // are requested before tile k's MFMA chain (the compiler fence keeps the scheduler from sinking them back next to
+    // their uses, where every MFMA would wait for its own LDS read).  T+2 = 34 rows: 8 tiles for every wave, a ninth
+    // for waves 0 and 1.
+    {
+      const char* xin = reinterpret_cast<const char*>(x1);
+      char* xout = reinterpret_cast<char*>(x2);
+      auto finish = [&](f32x4 acc, int k) {
+        const int row = r0 - 1 + wave + 4 * k;
+        half4 o = half4{0, 0, 0, 0};
+        if (row >= 0 && row < n_sc) o = relu_h4(acc);
+        if (col_ok) *reinterpret_cast<half4*>(xout + wr + k * 4 * ROW_BYTES16) = o;
+      };
+      constexpr int NK = DN_T / 4;
+      half8 fr[2][5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) fr[0][m] = *reinterpret_cast<const half8*>(xin + rd[m]);
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        if (k + 1 < NK) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) fr[(k + 1) & 1][m] = *reinterpret_cast<const half8*>(xin + rd[m] + (k + 1) * 4 * ROW_BYTES16);
+        }
+        asm volatile("" ::: "memory");
+        f32x4 acc = b2;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[m], fr[k & 1][m], acc, 0, 0, 0);
+        finish(acc, k);
+      }
+      if (wave < 2) {
+        f32x4 acc = b2;
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[m], *reinterpret_cast<const half8*>(xin + rd[m] + NK * 4 * ROW_BYTES16), acc, 0, 0, 0);
+        finish(acc, NK);
+      }
+    }
+    __syncthreads();
+    // ---- layer 3 + residual: x2 -> grid rows r0 .. r0+T-1 (c_out 0, 1 = re, im live in lanes 0..15)
+    {
+      const char* xin = reinterpret_cast<const char*>(x2);
+      half8 fr[2][5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) fr[0][m] = *reinterpret_cast<const half8*>(xin + rd[m]);
+#pragma unroll
+      for (int k = 0; k < DN_T / 4; ++k) {
+        if (k + 1 < DN_T / 4) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) fr[(k + 1) & 1][m] = *reinterpret_cast<const half8*>(xin + rd[m] + (k + 1) * 4 * ROW_BYTES16);
+        }
+        asm volatile("" ::: "memory");
+        f32x4 acc = b3;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[m], fr[k & 1][m], acc, 0, 0, 0);
+        if ((!(DN_ABLATE & 1) || acc[0] == 123.456f) && r0 + wave + 4 * k < n_sc && h_lane)
+          sb[h_off + 4 * k * CE_DN_SYMBOLS * L] = make_float2(hres[k].x + acc[0], hres[k].y + acc[1]);
+      }
+    }
+    // no barrier here: layer 1 of the next strip writes x1, which every wave finished reading before the barrier
+    // above; x2 is rewritten only after the next strip's first barrier, i.e. after every wave left this loop
+  }
+}
+
+_Float16 to_h(float v) { return (_Float16)v; }
+
+}  // namespace
+
+extern "C" int ce_denoiser_create(int32_t device, const float* w1, const float* b1, const float* w2, const float* b2,
+                                  const float* w3, const float* b3, ce_denoiser** out) {
+  if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out) return ce_fail(CE_ERR_INVALID, "null argument");
+  // fragment f, lane (row = c_out = lane & 15, g = lane >> 4), element j: the weight that multiplies B's k = 8 g + j
+  std::vector<_Float16> frag(11 * 64 * 8, to_h(0.f));
+  auto at = [&](int f, int lane, int j) -> _Float16& { return frag[((size_t)f * 64 + lane) * 8 + j]; };
+  for (int lane = 0; lane < 64; ++lane) {
+    const int co = lane & 15, g = lane >> 4;
+    for (int j = 0; j < 8; ++j) {  // layer 1: k = 8 g + j = 2 tap + (re | im)
+      const int k = 8 * g + j, tap = k >> 1, ci = k & 1;
+      if (tap < 9) at(0, lane, j) = to_h(w1[(co * 2 + ci) * 9 + tap]);
+    }
+    for (int m = 0; m < 5; ++m)
+      for (int j = 0; j < 8; ++j) {  // 16-channel layers: K-step m covers taps 2m, 2m+1; k = 16 (tap & 1) + c_in
+        const int tap = 2 * m + (g >> 1), ci = 8 * (g & 1) + j;
+        if (tap < 9) {
+          at(1 + m, lane, j) = to_h(w2[(co * 16 + ci) * 9 + tap]);
+          if (co < 2) at(6 + m, lane, j) = to_h(w3[(co * 16 + ci) * 9 + tap]);
+        }
+      }
+  }
+  float bias[48] = {0};
+  for (int i = 0; i < 16; ++i) { bias[i] = b1[i]; bias[16 + i] = b2[i]; }
+  bias[32] = b3[0];
+  bias[33] = b3[1];
+  ce_denoiser* d = new ce_denoiser;
+  d->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc(&d->wfrag, frag.size() * sizeof(_Float16));
+  if (e == hipSuccess) e = hipMalloc(&d->bias, sizeof(bias));
+  if (e == hipSuccess) e = hipMemcpy(d->wfrag, frag.data(), frag.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d->bias, bias, sizeof(bias), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    ce_denoiser_destroy(d);
+    return ce_fail(CE_ERR_HIP, "denoiser upload: %s", hipGetErrorString(e));
+  }
+  *out = d;
+  return CE_OK;
+}
+
+extern "C" void ce_denoiser_destroy(ce_denoiser* d) {
+  if (!d) return;
+  if (d->wfrag) (void)hipFree(d->wfrag);
+  if (d->bias) (void)hipFree(d->bias);
+  delete d;
+}
+
+extern "C" int ce_denoise_batch(const ce_denoiser* d, void* ch_est, int64_t n_items, int32_t n_sc, int32_t n_sym,
+                                int32_t n_layers, void* stream) {
+  if (!d || (!ch_est && n_items > 0)) return ce_fail(CE_ERR_INVALID, "null argument");
+  if (n_sym != CE_DN_SYMBOLS) return ce_fail(CE_ERR_UNSUPPORTED, "the denoiser is built for 14-symbol grids (got %d)", n_sym);
+  if (n_items < 0 || n_sc < 1 || n_layers < 1 || n_layers > CE_MAX_LAYERS) return ce_fail(CE_ERR_INVALID, "bad shape");
+  const int64_t planes = n_items * n_layers;
+  if (planes == 0) return CE_OK;
+  if (planes > 0x7FFFFFFFll) return ce_fail(CE_ERR_UNSUPPORTED, "%lld planes in one launch", (long long)planes);
+  hipLaunchKernelGGL(ce_denoise_kernel, dim3((unsigned)planes), dim3(DN_NT), 0, (hipStream_t)stream,
+                     reinterpret_cast<float2*>(ch_est), d->wfrag, d->bias, n_sc, n_layers);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CE_OK : ce_fail(CE_ERR_HIP, "denoise launch: %s", hipGetErrorString(e));
+}

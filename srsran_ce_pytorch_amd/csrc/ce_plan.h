@@ -103,6 +103,9 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
   return l;
 }
 
+// sets the calling thread's ce_last_error() text and returns `code` (ce_api.hip)
+int ce_fail(int code, const char* fmt, ...);
+
 int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,
               const float2* tw, const CeKernelArgs& args, int lds_bytes, int grid_cap, hipStream_t stream);
 int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int reg_kpt, int lds_bytes, int* blocks_per_cu);

@@ -41,7 +41,7 @@ def main():
         flags, _, ksrc = flags.partition("@")          # name=flags@kernel_source (default: the tree's ce_kernels.hip)
         kfile = str(ROOT / ksrc) if ksrc else str(csrc / "ce_kernels.hip")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT/'include'}", f"-I{csrc}",
-               "-o", "/tmp/libce_hip_ablate.so", str(csrc / "ce_api.hip"), kfile] + flags.split()
+               "-o", "/tmp/libce_hip_ablate.so", str(csrc / "ce_api.hip"), str(csrc / "ce_denoise.hip"), kfile] + flags.split()
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         r = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), a.slots, a.ports, a.smoothing, a.layers)], capture_output=True, text=True,
                            env=dict(os.environ, CE_HIP_LIB="/tmp/libce_hip_ablate.so"))   # never touches the shipped library  # stderr (compiler warnings) dropped

@@ -9,7 +9,7 @@ sys.path.insert(0, str(ROOT))
 csrc = ROOT / "srsran_ce_pytorch_amd" / "csrc"
 flags = sys.argv[1:] 
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT/'include'}", f"-I{csrc}", "-DCE_STAMPS=1",
-                "-o", "/tmp/libce_hip_stamps.so", str(csrc / "ce_api.hip"), str(csrc / "ce_kernels.hip")] + flags, check=True)
+                "-o", "/tmp/libce_hip_stamps.so", str(csrc / "ce_api.hip"), str(csrc / "ce_denoise.hip"), str(csrc / "ce_kernels.hip")] + flags, check=True)
 import os
 os.environ["CE_HIP_LIB"] = "/tmp/libce_hip_stamps.so"      # never overwrite the shipped library with a diagnostic build
 import torch
