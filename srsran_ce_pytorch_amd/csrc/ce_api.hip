@@ -439,7 +439,8 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     *out = p;
     return CE_OK;
   }
-  hipError_t e = hipSetDevice(d->device);
+  CeDeviceScope scope(d->device);  // the caller's current device is restored on return
+  hipError_t e = scope.err;
   if (e == hipSuccess) e = hipMalloc(&p->dev_plan, sizeof(CeDevPlan));
   if (e == hipSuccess) e = hipMalloc(&p->dev_re_idx, re_idx.size() * sizeof(uint16_t));
   if (e == hipSuccess) e = hipMalloc(&p->dev_tw, tw.size() * sizeof(float2));
@@ -531,6 +532,8 @@ int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_stri
   int rc = check_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, &a);
   if (rc != CE_OK) return rc;
   if (a.n_items == 0) return CE_OK;
+  CeDeviceScope scope(plan->device);  // `stream` belongs to the plan's device
+  if (scope.err != hipSuccess) return fail(CE_ERR_HIP, "device %d: %s", plan->device, hipGetErrorString(scope.err));
   int e = ce_launch(plan->host, plan->dev_plan, plan->dev_re_idx, plan->dev_ta_inv, plan->dev_tw, a, plan->info.lds_bytes, plan->grid_cap, (hipStream_t)stream);
   if (e != 0) return fail(CE_ERR_HIP, "kernel launch failed: %s", e > 0 ? hipGetErrorString((hipError_t)e) : "no kernel for this (layers, hops)");
   return CE_OK;
@@ -546,20 +549,25 @@ int ce_time_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[
     int rc = ce_estimate_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, stream);
     if (rc != CE_OK) return rc;
   }
+  CeDeviceScope scope(plan ? plan->device : 0);
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(hipEventRecord(e0, st));
-  for (int i = 0; i < iters; ++i) {
-    int rc = ce_estimate_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, stream);
-    if (rc != CE_OK) return rc;
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    return fail(CE_ERR_HIP, "hipEventCreate failed");
   }
-  HIP_TRY(hipEventRecord(e1, st));
-  HIP_TRY(hipEventSynchronize(e1));
+  hipError_t he = hipEventRecord(e0, st);
+  int rc = CE_OK;
+  for (int i = 0; i < iters && rc == CE_OK && he == hipSuccess; ++i)
+    rc = ce_estimate_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, stream);
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (he == hipSuccess) he = hipEventRecord(e1, st);
+  if (he == hipSuccess) he = hipEventSynchronize(e1);
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (rc != CE_OK) return rc;
+  if (he != hipSuccess) return fail(CE_ERR_HIP, "timing events: %s", hipGetErrorString(he));
   *avg_ms = (double)ms / iters;
   return CE_OK;
 }

@@ -282,7 +282,8 @@ extern "C" int ce_denoiser_create(int32_t device, const float* w1, const float* 
   bias[33] = b3[1];
   ce_denoiser* d = new ce_denoiser;
   d->device = device;
-  hipError_t e = hipSetDevice(device);
+  CeDeviceScope scope(device);
+  hipError_t e = scope.err;
   if (e == hipSuccess) e = hipMalloc(&d->wfrag, frag.size() * sizeof(_Float16));
   if (e == hipSuccess) e = hipMalloc(&d->bias, sizeof(bias));
   if (e == hipSuccess) e = hipMemcpy(d->wfrag, frag.data(), frag.size() * sizeof(_Float16), hipMemcpyHostToDevice);
@@ -310,6 +311,8 @@ extern "C" int ce_denoise_batch(const ce_denoiser* d, void* ch_est, int64_t n_it
   const int64_t planes = n_items * n_layers;
   if (planes == 0) return CE_OK;
   if (planes > 0x7FFFFFFFll) return ce_fail(CE_ERR_UNSUPPORTED, "%lld planes in one launch", (long long)planes);
+  CeDeviceScope scope(d->device);
+  if (scope.err != hipSuccess) return ce_fail(CE_ERR_HIP, "device %d: %s", d->device, hipGetErrorString(scope.err));
   hipLaunchKernelGGL(ce_denoise_kernel, dim3((unsigned)planes), dim3(DN_NT), 0, (hipStream_t)stream,
                      reinterpret_cast<float2*>(ch_est), d->wfrag, d->bias, n_sc, n_layers);
   const hipError_t e = hipGetLastError();

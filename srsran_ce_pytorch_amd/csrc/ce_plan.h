@@ -103,6 +103,25 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
   return l;
 }
 
+// Makes `device` current for the scope and restores the caller's device afterwards (no HIP call when it already is).
+struct CeDeviceScope {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit CeDeviceScope(int device) {
+    int cur = -1;
+    err = hipGetDevice(&cur);
+    if (err == hipSuccess && cur != device) {
+      err = hipSetDevice(device);
+      if (err == hipSuccess) prev = cur;
+    }
+  }
+  ~CeDeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  CeDeviceScope(const CeDeviceScope&) = delete;
+  CeDeviceScope& operator=(const CeDeviceScope&) = delete;
+};
+
 // sets the calling thread's ce_last_error() text and returns `code` (ce_api.hip)
 int ce_fail(int code, const char* fmt, ...);
 

@@ -38,7 +38,7 @@ def _case(n_prbs, smoothing, layers, seed):
     return S.case_spec("prop", 52, [S.hop_spec([2, 11], 3, n_prbs, re_masks=masks)], n_layers=layers, smoothing=smoothing, seed=seed)
 
 
-@settings(max_examples=12, deadline=None)
+@settings(max_examples=12, deadline=None, derandomize=True)
 @given(n_prbs=st.integers(3, 30), smoothing=st.sampled_from(["none", "mean", "filter"]), layers=st.integers(1, 4), seed=st.integers(0, 10_000))
 def test_oracle_scaling_and_rotation_invariants(n_prbs, smoothing, layers, seed):
     b = S.build_case(_case(n_prbs, smoothing, layers, seed), 1)
@@ -50,7 +50,8 @@ def test_oracle_scaling_and_rotation_invariants(n_prbs, smoothing, layers, seed)
     assert twice[4] == base[4] and twice[5] == pytest.approx(base[5], rel=1e-9, abs=1e-9)
     rot = np.complex64(np.exp(0.7j))
     turned = O.srs_channel_estimator(b.grids[0] * rot, b.pilots, b.beta, b.hop1, b.hop2, b.config)
-    assert np.abs(turned[0] - base[0] * rot).max() <= 5e-6 * np.abs(base[0]).max()
+    # float32 rounding scales with the pilots that were averaged, not with the result (a band mean can cancel to ~0.01)
+    assert np.abs(turned[0] - base[0] * rot).max() <= 5e-6 * max(np.abs(base[0]).max(), np.abs(b.grids[0]).max())
     assert turned[4] == base[4]
     # zeros outside the allocation, hop band fully populated
     assert not base[0][: 36].any() and not base[0][12 * (3 + n_prbs):].any()
