@@ -8,7 +8,10 @@
 //   B = activations [K 32][16 columns of one subcarrier row], K = 2 taps x 16 input channels:
 //       lane l: column l&15, tap 2m + (l>>5), channels 8((l>>4)&1) .. +7  -> one ds_read_b128 per MFMA
 //   D lane l: column l&15, c_out 4(l>>4)+i -> one ds_write_b64 per tile.
-// 9 taps = 4.5 K-steps -> 5 MFMAs per (row, layer); tap 9 has zero weights and re-reads tap 8's address.
+// 9 taps = 4.5 K-steps -> 5 MFMAs per row of layer 2; tap 9 has zero weights and re-reads tap 8's address.
+// Layer 3 has only 2 output channels, so its 16 MFMA rows hold (4 subcarrier rows x re|im, 8 rows used) and K runs over
+// the 6 input rows x 3 symbol taps x 16 channels that a block of 4 output rows sees (9 K-steps; the weight matrix is
+// banded: a row's 3 x 3 taps, zeros elsewhere) -- 9 MFMAs and 9 LDS reads per 4 rows instead of 20.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -25,7 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ce_denoiser {
   int device = 0;
-  half8* wfrag = nullptr;  // [11][64]: layer 1 (1 K-step), layer 2 (5), layer 3 (5)
+  half8* wfrag = nullptr;  // [15][64]: layer 1 (1 K-step), layer 2 (5), layer 3 (9, banded over a 4-row block)
   float* bias = nullptr;   // [3][16]
 };
 
@@ -77,18 +80,17 @@ __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ 
   const int l = (int)(plane - item * L);
   float2* base = ch + item * (int64_t)n_sc * CE_DN_SYMBOLS * L + l;
 
-  half8 w1 = wfrag[lane], w2[5], w3[5];
+  half8 w1 = wfrag[lane], w2[5], w3[9];
 #pragma unroll
-  for (int m = 0; m < 5; ++m) {
-    w2[m] = wfrag[(1 + m) * 64 + lane];
-    w3[m] = wfrag[(6 + m) * 64 + lane];
-  }
+  for (int m = 0; m < 5; ++m) w2[m] = wfrag[(1 + m) * 64 + lane];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) w3[m] = wfrag[(6 + m) * 64 + lane];
   f32x4 b1, b2, b3;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     b1[i] = bias[4 * g + i];
     b2[i] = bias[16 + 4 * g + i];
-    b3[i] = bias[32 + 4 * g + i];
+    b3[i] = g < 2 ? bias[32 + (i & 1)] : 0.f;  // layer-3 D rows: (subcarrier row 2g + (i >> 1), re | im)
   }
   // pad pixels and padding columns are read but never written: zero the images once
   for (int i = tid; i < 2 * X0_PIX; i += DN_NT) (&x0[0][0])[i] = half2v{0, 0};
@@ -128,8 +130,19 @@ __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ 
     st_ok[k] = i < (DN_T + 6) * DN_COLS && sym >= 0 && sym < CE_DN_SYMBOLS;
     st_off[k] = (st_row[k] * CE_DN_SYMBOLS + sym) * L;
   }
-  const int h_off = (wave * CE_DN_SYMBOLS + (n - 1)) * L;  // residual / output of image row wave (+ 4k rows per tile)
-  const bool h_lane = g == 0 && col_ok;
+  // layer 3: K-step j of a block reads input row j/3 + 3 (g >> 1), symbol tap j % 3, channels 8 (g & 1) .. +7; the block
+  // of a wave starts at x2 image row 4 wave (+ 16 for its second block).  One base per symbol tap (the half swap depends
+  // on it), rows are compile-time offsets.
+  int rd3[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int pix = 1 + (4 * wave + 3 * (g >> 1)) * DN_COLS + n + dx - 1;
+    rd3[dx] = pix * (DN_C * 2) + (((g & 1) ^ ((pix >> 2) & 1)) * 16);
+  }
+  // lanes g = 0, 1 hold the block's rows 2g and 2g + 1 (re, im each) of column n
+  const int h_row = 4 * wave + 2 * g;                           // strip-relative subcarrier row of acc[0..1]
+  const int h_off = (h_row * CE_DN_SYMBOLS + (n - 1)) * L;
+  const bool h_lane = g < 2 && col_ok;
 
   float2 st[ST_N];
   auto stage_load = [&](int r0) {  // rows r0-3 .. r0+T+2 -> registers (zeros outside the grid)
@@ -159,12 +172,14 @@ __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ 
     // The next strip's input rows overlap this strip's output rows: request them (and this strip's float32 residuals)
     // now, before layer 3 overwrites them; they are consumed after layer 1 / in layer 3.
     if (s + 1 < n_strips) stage_load(r0 + DN_T);
-    float2 hres[DN_T / 4];
+    float2 hres[2][2];  // [block][row 2g + e]: float32 residuals of this lane's four outputs
 #pragma unroll
-    for (int k = 0; k < DN_T / 4; ++k) {
-      hres[k] = make_float2(0.f, 0.f);
-      if (!(DN_ABLATE & 2) && r0 + wave + 4 * k < n_sc && h_lane) hres[k] = sb[h_off + 4 * k * CE_DN_SYMBOLS * L];
-    }
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        hres[b][e] = make_float2(0.f, 0.f);
+        if (!(DN_ABLATE & 2) && h_lane && r0 + h_row + 16 * b + e < n_sc) hres[b][e] = sb[h_off + (16 * b + e) * CE_DN_SYMBOLS * L];
+      }
     // ---- layer 1: x0 -> x1 image rows 0 .. T+3 (image row t <-> grid row r0-2+t); K = (tap, re | im)
     {
       const char* xin = reinterpret_cast<const char*>(&x0[buf][0]);
@@ -226,24 +241,21 @@ __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ 
       }
     }
     __syncthreads();
-    // ---- layer 3 + residual: x2 -> grid rows r0 .. r0+T-1 (c_out 0, 1 = re, im live in lanes 0..15)
+    // ---- layer 3 + residual: x2 -> grid rows r0 .. r0+T-1, two blocks of 4 rows per wave (rows 4 wave + 16 b ..)
     {
       const char* xin = reinterpret_cast<const char*>(x2);
-      half8 fr[2][5];
 #pragma unroll
-      for (int m = 0; m < 5; ++m) fr[0][m] = *reinterpret_cast<const half8*>(xin + rd[m]);
+      for (int b = 0; b < 2; ++b) {
+        half8 fr[9];
 #pragma unroll
-      for (int k = 0; k < DN_T / 4; ++k) {
-        if (k + 1 < DN_T / 4) {
-#pragma unroll
-          for (int m = 0; m < 5; ++m) fr[(k + 1) & 1][m] = *reinterpret_cast<const half8*>(xin + rd[m] + (k + 1) * 4 * ROW_BYTES16);
-        }
-        asm volatile("" ::: "memory");
+        for (int j = 0; j < 9; ++j) fr[j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (16 * b + j / 3) * ROW_BYTES16);
         f32x4 acc = b3;
 #pragma unroll
-        for (int m = 0; m < 5; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[m], fr[k & 1][m], acc, 0, 0, 0);
-        if ((!(DN_ABLATE & 1) || acc[0] == 123.456f) && r0 + wave + 4 * k < n_sc && h_lane)
-          sb[h_off + 4 * k * CE_DN_SYMBOLS * L] = make_float2(hres[k].x + acc[0], hres[k].y + acc[1]);
+        for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[j], fr[j], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          if ((!(DN_ABLATE & 1) || acc[0] == 123.456f) && h_lane && r0 + h_row + 16 * b + e < n_sc)
+            sb[h_off + (16 * b + e) * CE_DN_SYMBOLS * L] = make_float2(hres[b][e].x + acc[2 * e], hres[b][e].y + acc[2 * e + 1]);
       }
     }
     // no barrier here: layer 1 of the next strip writes x1, which every wave finished reading before the barrier
@@ -259,7 +271,7 @@ extern "C" int ce_denoiser_create(int32_t device, const float* w1, const float* 
                                   const float* w3, const float* b3, ce_denoiser** out) {
   if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out) return ce_fail(CE_ERR_INVALID, "null argument");
   // fragment f, lane (row = c_out = lane & 15, g = lane >> 4), element j: the weight that multiplies B's k = 8 g + j
-  std::vector<_Float16> frag(11 * 64 * 8, to_h(0.f));
+  std::vector<_Float16> frag(15 * 64 * 8, to_h(0.f));
   auto at = [&](int f, int lane, int j) -> _Float16& { return frag[((size_t)f * 64 + lane) * 8 + j]; };
   for (int lane = 0; lane < 64; ++lane) {
     const int co = lane & 15, g = lane >> 4;
@@ -270,11 +282,16 @@ extern "C" int ce_denoiser_create(int32_t device, const float* w1, const float* 
     for (int m = 0; m < 5; ++m)
       for (int j = 0; j < 8; ++j) {  // 16-channel layers: K-step m covers taps 2m, 2m+1; k = 16 (tap & 1) + c_in
         const int tap = 2 * m + (g >> 1), ci = 8 * (g & 1) + j;
-        if (tap < 9) {
-          at(1 + m, lane, j) = to_h(w2[(co * 16 + ci) * 9 + tap]);
-          if (co < 2) at(6 + m, lane, j) = to_h(w3[(co * 16 + ci) * 9 + tap]);
-        }
+        if (tap < 9) at(1 + m, lane, j) = to_h(w2[(co * 16 + ci) * 9 + tap]);
       }
+    // layer 3, banded over a block of 4 output rows: D row = 2 r + (re | im), r = 0..3 (rows 8..15 unused); K-step m,
+    // lane group g: input row ri = m / 3 + 3 (g >> 1) of the block's 6, symbol tap dx = m % 3, channels 8 (g & 1) + j
+    if (co < 8)
+      for (int m = 0; m < 9; ++m)
+        for (int j = 0; j < 8; ++j) {
+          const int r = co >> 1, c3 = co & 1, ri = m / 3 + 3 * (g >> 1), dx = m % 3, ci = 8 * (g & 1) + j, ky = ri - r;
+          if (ky >= 0 && ky <= 2) at(6 + m, lane, j) = to_h(w3[(c3 * 16 + ci) * 9 + ky * 3 + dx]);
+        }
   }
   float bias[48] = {0};
   for (int i = 0; i < 16; ++i) { bias[i] = b1[i]; bias[16 + i] = b2[i]; }

@@ -23,6 +23,6 @@ for _ in range(3):
     best = min(best, e0.elapsed_time(e1) / 3)
 planes = slots * 4
 flops = planes * 3276 * 14 * 2 * (2 * 16 * 9 + 16 * 16 * 9 + 16 * 2 * 9)
-issued = planes * 3276 * 14 / 14 * (36 / 32 * 1 + 34 / 32 * 5 + 5) * 16 * 16 * 32 * 2
+issued = planes * (3276 / 32) * (36 * 1 + 34 * 5 + 8 * 9) * 16 * 16 * 32 * 2   # MFMAs per 32-row strip: layer 1, layer 2, layer 3 (banded 4-row blocks)
 print(f"{slots} slots x 4: {best:.3f} ms  useful {flops / best / 1e9:.1f} TFLOP/s  issued-MFMA {issued / best / 1e9:.1f} TFLOP/s  "
       f"bytes {planes * 3276 * 14 * 16 / best / 1e6:.0f} GB/s  max|err| vs oracle {err:.2e}")
