@@ -184,15 +184,22 @@ __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ 
     {
       const char* xin = reinterpret_cast<const char*>(&x0[buf][0]);
       char* xout = reinterpret_cast<char*>(x1);
+      constexpr int NK1 = (DN_T + 4) / 4;
+      half2v px[2][4];  // tile k+1's pixels are requested before tile k's MFMA (same fence as in layer 2)
 #pragma unroll
-      for (int k = 0; k < (DN_T + 4) / 4; ++k) {
+      for (int q = 0; q < 4; ++q) px[0][q] = *reinterpret_cast<const half2v*>(xin + rd0[q]);
+#pragma unroll
+      for (int k = 0; k < NK1; ++k) {
+        if (k + 1 < NK1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) px[(k + 1) & 1][q] = *reinterpret_cast<const half2v*>(xin + rd0[q] + (k + 1) * 4 * ROW_BYTES0);
+        }
+        asm volatile("" ::: "memory");
         half8 b;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // taps >= 9 (K padding) have zero weights: whatever finite pixel their lanes read does not matter
-          const half2v v = *reinterpret_cast<const half2v*>(xin + rd0[q] + k * 4 * ROW_BYTES0);
-          b[2 * q] = v[0];
-          b[2 * q + 1] = v[1];
+        for (int q = 0; q < 4; ++q) {  // taps >= 9 (K padding) have zero weights: whatever finite pixel their lanes read does not matter
+          b[2 * q] = px[k & 1][q][0];
+          b[2 * q + 1] = px[k & 1][q][1];
         }
         const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b, b1, 0, 0, 0);
         const int row = r0 - 2 + wave + 4 * k;  // wave-uniform: outside the grid the next layer must see zero padding
@@ -244,14 +251,19 @@ __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ 
     // ---- layer 3 + residual: x2 -> grid rows r0 .. r0+T-1, two blocks of 4 rows per wave (rows 4 wave + 16 b ..)
     {
       const char* xin = reinterpret_cast<const char*>(x2);
+      half8 fr[2][9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) fr[0][j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (j / 3) * ROW_BYTES16);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        half8 fr[9];
+        if (b == 0) {
 #pragma unroll
-        for (int j = 0; j < 9; ++j) fr[j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (16 * b + j / 3) * ROW_BYTES16);
+          for (int j = 0; j < 9; ++j) fr[1][j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (16 + j / 3) * ROW_BYTES16);
+        }
+        asm volatile("" ::: "memory");
         f32x4 acc = b3;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[j], fr[j], acc, 0, 0, 0);
+        for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[j], fr[b][j], acc, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
           if ((!(DN_ABLATE & 1) || acc[0] == 123.456f) && h_lane && r0 + h_row + 16 * b + e < n_sc)
