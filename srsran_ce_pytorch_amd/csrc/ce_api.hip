@@ -374,7 +374,21 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     int lg = 8;
     while (lg < 12 && P.n_hops * L * (2 << lg) * 8 <= need) ++lg;
     P.wr_ch_log2 = lg;
-    if (d->interp == CE_INTERP_CNN) {
+    // A comb-2 DM-RS (every other RE, either offset) makes the partial-convolution in-painting of C:473-508 reach its
+    // fixed point -- the mean of the two neighbouring pilots -- after two iterations (the float32 round trip of C:501
+    // absorbs the 1/(1+1e-12) factor of the remaining max(6, n/8) - 2), and the two low-pass passes then give
+    // (P[k-1] + 15 P[k] + 15 P[k+1] + P[k+2]) / 32 with reflected pilot indices at the band edges: the writer evaluates
+    // that straight from P, no whole-band staging (measured against the real ce_dl_cnn.py fixtures like the general form).
+    P.cnn_comb2 = 0;
+    if (d->interp == CE_INTERP_CNN && !getenv("CE_CNN_GENERAL")) {  // env: tuning / A-B knob
+      P.cnn_comb2 = 1;
+      for (int h = 0; h < d->n_hops; ++h)
+        for (int c = 0; c < n_cdm; ++c) {
+          const unsigned m12 = (P.hop[h].mask12 >> (16 * c)) & 0xFFFu;
+          if (m12 != 0x555u && m12 != 0xAAAu) P.cnn_comb2 = 0;
+        }
+    }
+    if (d->interp == CE_INTERP_CNN && !P.cnn_comb2) {
       // whole-band H rows for every (hop, layer) + a second x buffer + two mask byte arrays
       int n_max = 0;
       for (int h = 0; h < d->n_hops; ++h) n_max = P.hop[h].n_sc_hop > n_max ? P.hop[h].n_sc_hop : n_max;
@@ -385,6 +399,8 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       P.cnn_m_off = h_bytes + ((n_max + 1) & ~1) * 8;
       const int cnn_need = P.cnn_m_off + 2 * ((n_max + 15) & ~15);
       if (cnn_need > P.scratch_bytes) P.scratch_bytes = cnn_need;
+    }
+    if (d->interp == CE_INTERP_CNN) {
       double a = d->cnn_smoothing_alpha;
       P.cnn_alpha = (float)(a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a));
       for (int c = 0; c < 5; ++c) P.cnn_rcp[c] = 1.0 / (0.25 * c + 1e-12);

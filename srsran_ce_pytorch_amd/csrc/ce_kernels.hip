@@ -446,6 +446,9 @@ __device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils
   __syncthreads();
 }
 
+template <int SC_STEP>
+__device__ constexpr bool direct_ok() { return SC_STEP % 12 == 0; }  // whole-PRB steps: L = 1, 3
+
 // Grid writer, direct form (L = 1, 3; 14 symbols): each of 252 threads owns ONE (symbol, layer) float4 phase of
 // the 7L float4 a subcarrier spans, so its two CFO phasors and hop/layer selection are thread constants and a
 // workgroup iteration stores 4032 contiguous bytes.  Its subcarriers advance by whole PRBs, so its RE position
@@ -1186,6 +1189,21 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
     return make_float2(u.x + t.x * (v.x - u.x), u.y + t.x * (v.y - u.y));
   };
 
+  // ce_dl_cnn.py's in-painting + two low-pass passes for a comb-2 DM-RS, closed form (ce_api.hip: cnn_comb2): pilots
+  // keep their value (C:507-508), an RE between pilots k and k+1 gets (P[k-1] + 15 P[k] + 15 P[k+1] + P[k+2]) / 32, pilot
+  // indices outside the band reflected the way the RE-domain reflect padding (C:433-451) maps them.
+  auto cnn2_at = [&](int h, int l, int p) -> float2 {
+    const CeDevHop& lh = lp->hop[h];
+    const int off = ((lh.mask12 >> (16 * (l >> 1))) & 1u) ? 0 : 1;  // pilots on even or on odd REs
+    const float2* Pl = P + (h * L + l) * n_re_pad;
+    const int q = p - off, K = n_re - 1;
+    if (q >= 0 && !(q & 1)) return Pl[q >> 1];
+    const int kl = (q - 1) >> 1;  // pilot on the left (-1: the RE in front of the first pilot)
+    auto refl = [&](int k) { return k < 0 ? -k - off : (k > K ? 2 * K + 1 - off - k : k); };
+    const float2 a = Pl[refl(kl - 1)], b = Pl[refl(kl)], c = Pl[refl(kl + 1)], d2 = Pl[refl(kl + 2)];
+    return make_float2(((a.x + d2.x) + 15.f * (b.x + c.x)) * (1.f / 32.f), ((a.y + d2.y) + 15.f * (b.y + c.y)) * (1.f / 32.f));
+  };
+
   if (CE_ABLATE & 8) {
   } else if (n_sym == CE_MAX_SYMBOLS && !lp->sym_overlap) {
     // Fast writer (hop of an element decided by its symbol alone).  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
@@ -1212,7 +1230,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
       rsel[e] = h < 0 ? make_float2(0.f, 0.f) : rot_final[sym];  // rot_final == 1 when no CFO ramp applies
     }
     float4* out4 = reinterpret_cast<float4*>(out);
-    if (lp->interp == CE_INTERP_CNN) {
+    if (lp->interp == CE_INTERP_CNN && !lp->cnn_comb2) {
       // in-painted response for every (hop, layer), whole band at once, then the same phase-owning store loop
       const int hs = lp->cnn_h_stride, n_sc = lp->n_sc;
       float2* pong = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(scratch) + lp->cnn_pong_off);
@@ -1243,8 +1261,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
           o += ACTIVE;
         }
       }
-    } else if constexpr (SC_STEP % 12 == 0) {
-      write_grid_direct<L, NH>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);
+    } else if (direct_ok<SC_STEP>() && lp->interp != CE_INTERP_CNN) {
+      if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);
     } else {
       const float2* HA = scratch + ((hsel[0] * L + lsel[0]) << ch_log2);
       const float2* HB = scratch + ((hsel[1] * L + lsel[1]) << ch_log2);
@@ -1257,7 +1275,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
             const int h = hl / L, l = hl - h * L;
             const int p = c0 + s - lp->hop[h].sc0;
             float2 v = make_float2(0.f, 0.f);
-            if (p >= 0 && p < lp->hop[h].n_sc_hop) v = interp_at(h, l, p);
+            if (p >= 0 && p < lp->hop[h].n_sc_hop) v = lp->interp == CE_INTERP_CNN ? cnn2_at(h, l, p) : interp_at(h, l, p);
             scratch[i] = v;
           }
         }

@@ -69,6 +69,10 @@ def golden_cases():
         (dict(CS("cnn_alpha05_3prb", 52, [H([2, 11], 7, 3)], seed=22), cnn_alpha=0.5), "C", 1),
         (dict(CS("cnn_layers2_alpha", 52, [H([2, 11], 5, 6)], n_layers=2, seed=24), cnn_alpha=0.3), "C", 1),
         (dict(S.bench_case("filter", seed=77), name="cnn_pusch273_filter"), "C", 1),
+        # comb-2 masks on odd REs / in two CDM groups / on a single PRB: the closed-form writer's reflected band edges
+        (CS("cnn_comb2_odd_3prb", 52, [H([2, 11], 9, 3, re_masks=[S.TYPE1_CDM1])], smoothing="none", seed=25), "C", 2),   # (>= 18 pilots: with <= 12 the TA peak is flat to float32 rounding)
+        (dict(CS("cnn_layers4_comb2", 52, [H([2, 7, 11], 20, 7, re_masks=BOTH)], n_layers=4, seed=26), cnn_alpha=0.25), "C", 1),
+        (CS("cnn_comb2_odd_2hop", 52, [H([3], 0, 5, 0, 7, [S.TYPE1_CDM1]), H([10], 47, 5, 7, 7, [S.TYPE1_CDM1])], smoothing="mean", seed=27), "C", 1),
     ]
     return cases
 
