@@ -34,6 +34,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_MW4_LIMIT
 #define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
 #endif
+#ifndef CE_NH2_MW4_LIMIT
+#define CE_NH2_MW4_LIMIT 2   // two hops: up to this many pilot REs x symbols per thread, 4 workgroups per CU (4-8 spilled VGPRs; measured +6..12 % on narrow hops, nothing at 4)
+#endif
 #ifndef CE_NH2_MW2_FROM
 #define CE_NH2_MW2_FROM 15  // two hops: from this many pilot REs x symbols per thread on, 2 workgroups per CU with everything in registers
 #endif
@@ -45,7 +48,7 @@ constexpr int ce_min_waves(int nh, int nd, int kpt) {
   const int n = nd * kpt;
   if (nd == 0) return CE_MIN_WAVES;
   if (nh == 1) return n <= CE_MW4_LIMIT ? 4 : n <= 14 ? CE_MIN_WAVES : 2;
-  return n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
+  return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
 }
 constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
   const int n = nd * kpt;

@@ -18,6 +18,9 @@ cases = [
     ("L1 2 hops x 2dmrs 200 PRB", CS("h2w", 273, [H([1, 5], 0, 200, 0, 7), H([8, 12], 73, 200, 7, 7)]), "linear"),
     ("L1 2 hops x 3dmrs 136 PRB", CS("h2d3", 273, [H([0, 3, 6], 0, 136, 0, 7), H([7, 10, 13], 137, 136, 7, 7)]), "linear"),
     ("L1 2 hops x 3dmrs 200 PRB", CS("h2d3w", 273, [H([0, 3, 6], 0, 200, 0, 7), H([7, 10, 13], 73, 200, 7, 7)]), "linear"),
+    ("L1 2 hops x 2dmrs 40 PRB in 106", CS("h2n", 106, [H([1, 5], 0, 40, 0, 7), H([8, 12], 60, 40, 7, 7)]), "linear"),
+    ("L1 2 hops x 1dmrs 12 PRB in 52", CS("h2t", 52, [H([2], 3, 12, 0, 7), H([9], 30, 12, 7, 7)]), "linear"),
+    ("L1 2 hops x 2dmrs 80 PRB in 273", CS("h2m", 273, [H([1, 5], 0, 80, 0, 7), H([8, 12], 150, 80, 7, 7)]), "linear"),
     ("L1 type-2 mask filter", CS("t2", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "linear"),
     ("L1 cnn in-painting", S.bench_case("filter", 1), "cnn"),
     ("L1 cnn type-2 mask", CS("t2c", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "cnn"),
