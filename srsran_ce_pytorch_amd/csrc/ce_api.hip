@@ -307,7 +307,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
 
   if (d->smoothing == CE_SMOOTH_FILTER) {
     const int dpp0 = P.hop[0].dpp[0];
-    if (12 % dpp0 != 0) { delete p; return fail(CE_ERR_UNSUPPORTED, "%d pilots per PRB does not divide 12 (T:640)", dpp0); }
+    // stride = 12 // pilots-per-PRB, floor division as the reference does (T:640) even when it does not divide 12
     const int n_active = d->hop[0].n_prbs;
     std::vector<double> rc = rc_taps(12 / dpp0, n_active < 3 ? n_active : 3);
     if ((int)rc.size() > CE_MAX_RC_TAPS) { delete p; return fail(CE_ERR_UNSUPPORTED, "%zu RC taps", rc.size()); }

@@ -191,7 +191,8 @@ def test_inputs_not_mutated_and_every_output_written():
 
 
 RE_MASKS = {"all12": [1] * 12, "every4th": [1, 0, 0, 0] * 3, "every6th": [1, 0, 0, 0, 0, 0] * 2, "single": [1] + [0] * 11,
-            "irregular": [1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0], "comb2_odd": [0, 1] * 6}
+            "irregular": [1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0], "comb2_odd": [0, 1] * 6,
+            "five": [1, 0, 1, 1, 0, 0, 1, 0, 0, 1, 0, 0], "seven": [1, 1, 0, 1, 1, 0, 1, 0, 1, 0, 1, 0]}   # 12 // 5 = 2, 12 // 7 = 1 (floor, T:640)
 
 
 @pytest.mark.parametrize("n_prbs", [8, 2, 1])

@@ -19,7 +19,8 @@ from conftest import check_outputs
 from srsran_ce_pytorch_amd import estimator as E, synth as S
 
 SINGLE = [S.TYPE1_CDM0, S.TYPE1_CDM1, S.TYPE2_CDM0, S.TYPE2_CDM1, [1] * 12, [1, 0, 0, 0] * 3, [0, 0, 1, 0] * 3,
-          [1, 0, 0, 0, 0, 0] * 2, [1] + [0] * 11, [1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0]]
+          [1, 0, 0, 0, 0, 0] * 2, [1] + [0] * 11, [1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0],
+          [1, 0, 1, 1, 0, 0, 1, 0, 0, 1, 0, 0], [1, 1, 0, 1, 1, 0, 1, 0, 1, 0, 1, 0], [1] * 11 + [0]]
 PAIRS = [[S.TYPE1_CDM0, S.TYPE1_CDM1], [S.TYPE2_CDM0, S.TYPE2_CDM1], [S.TYPE2_CDM1, [0, 0, 0, 0, 1, 1] * 2],
          [[1, 0, 0, 0] * 3, [0, 1, 0, 0] * 3], [S.TYPE1_CDM1, S.TYPE1_CDM0]]
 
@@ -72,7 +73,7 @@ def main():
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     dev = torch.device("cuda:0")
-    bad = unsupported = raised = near_ties = 0
+    bad = unsupported = raised = near_ties = illcond = 0
     for i in range(a.n):
         case, interp = draw(rng, a.max_grid)
         tag = json.dumps(dict(case, interp=interp))
@@ -142,6 +143,11 @@ def main():
                 got[3] = rs[3]
             if np.isfinite(rs[4]) and abs(got[4] - rs[4]) <= 5e-8 * case["scs"]:
                 got[4] = rs[4]                       # float32 floor of the CFO: |d angle| ~ 3e-7 rad whatever the angle
+            if scattered and np.isfinite(rs[4]) and abs(rs[4] - case["cfo_hz"]) > 50.0:
+                # the synthetic channel is laid out for the contiguous run, so with a scattered mask the CFO correlation is a
+                # sum of incoherent terms: its angle (and the ramp built from it) is ill-conditioned in float32 on BOTH sides
+                illcond += 1
+                break
             try:
                 # "mean" smoothing can cancel to a small band mean: float32 rounding scales with the pilots (|H| ~ 1), not the result
                 tol_ch = 2e-5 * max(1.0, 0.7 / float(np.abs(ref[0]).max())) if case["smoothing"] == "mean" else 2e-5
@@ -152,7 +158,7 @@ def main():
                 break
         if (i + 1) % 50 == 0:
             print(f"... {i + 1} cases, {bad} disagreements, {unsupported} unsupported, {raised} agreed errors", flush=True)
-    print(f"done: {a.n} cases, {bad} disagreements, {unsupported} unsupported, {raised} agreed errors, {near_ties} TA near-ties (one bin, <= 12 pilots)")
+    print(f"done: {a.n} cases, {bad} disagreements, {unsupported} unsupported, {raised} agreed errors, {near_ties} TA near-ties (one bin, <= 12 pilots), {illcond} skipped (incoherent CFO correlation under a scattered mask)")
     sys.exit(1 if bad else 0)
 
 
