@@ -282,6 +282,11 @@ def estimate(received_rg: torch.Tensor, pilots: torch.Tensor, beta_dmrs, hop1, h
         raise ValueError("n_sc must be a multiple of 12")
     plan = make_plan(hop1, hop2, config, beta_dmrs, pilots.shape[-1], n_sc // 12, n_sym, received_rg.device, interp)
     res = estimate_with_plan(plan, received_rg, pilots, out)
+    # EXTENSION (no reference counterpart): `config.Denoiser`, a srsran_ce_pytorch_amd.denoiser.Denoiser, post-processes
+    # the channel estimate in place on the same stream -- the reference reads optional attributes the same way (C:864)
+    denoiser = getattr(config, "Denoiser", None)
+    if denoiser is not None:
+        denoiser(res[0])
     if not plan.cfo_estimated:
         return res[:5] + (torch.empty((0,), dtype=torch.float64, device=received_rg.device),)
     return res

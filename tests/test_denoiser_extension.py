@@ -71,3 +71,26 @@ def test_hip_denoiser_zero_weights_and_errors():
     with pytest.raises(ValueError):
         Denoiser(dict(w, w2=np.zeros((16, 8, 3, 3), np.float32)))
     Denoiser(w)(torch.zeros(0, 50, 14, 1, dtype=torch.complex64, device="cuda:0"))    # empty batch: no launch
+
+
+@pytest.mark.gpu
+def test_denoiser_through_estimate_config_attribute():
+    """`config.Denoiser` (optional attribute, read like the reference reads CNNSmoothingAlpha): estimate() = estimation
+    followed by the in-place denoiser; the shim inherits it."""
+    import torch
+    from srsran_ce_pytorch_amd import estimator as E, synth as S
+    from srsran_ce_pytorch_amd.denoiser import Denoiser
+    case = S.case_spec("dn", 25, [S.hop_spec([2, 11], 2, 20)], seed=11)
+    b = S.build_case(case, 2)
+    g = torch.as_tensor(b.grids, device="cuda:0")[None]
+    p = torch.as_tensor(b.pilots, device="cuda:0")
+    plain = E.estimate(g, p, b.beta, b.hop1, b.hop2, b.config)
+    w = random_weights(2)
+    b.config.Denoiser = Denoiser(w)
+    den = E.estimate(g, p, b.beta, b.hop1, b.hop2, b.config)
+    want = DO.denoise(plain[0].cpu().numpy(), w)
+    assert np.abs(den[0].cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max()
+    for a, c in zip(plain[1:], den[1:]):
+        assert torch.equal(a, c)                                                # scalars untouched
+    one = E.srs_channel_estimator(g[0, 1], p, b.beta, b.hop1, b.hop2, b.config)
+    assert torch.allclose(one[0], den[0][0, 1], atol=1e-6)
