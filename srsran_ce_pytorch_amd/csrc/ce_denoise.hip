@@ -33,7 +33,7 @@ struct ce_denoiser {
 };
 
 #ifndef DN_ABLATE
-#define DN_ABLATE 0   // timing experiments only: 1 no global stores, 2 no global loads, 4 skip layer 1, 8 skip layer 2, 16 skip layer 3, 32 no barriers
+#define DN_ABLATE 0   // timing experiments only: 1 no global stores, 2 no global loads
 #endif
 
 namespace {
@@ -63,8 +63,8 @@ __device__ __forceinline__ half4 relu_h4(f32x4 acc) {
   return half4{lo[0], lo[1], hi[0], hi[1]};
 }
 
-// The kernel is bound by vector-instruction issue, not by the MFMAs, unless the per-tile bookkeeping is scalar or
-// constant: every LDS address below is a per-lane constant plus a compile-time tile offset (the tile loops are fully
+// The kernel is bound by vector-instruction issue (first version: 11.6 vector instructions per MFMA), not by the matrix
+// cores or the LDS, unless the per-tile bookkeeping is scalar or constant: every LDS address below is a per-lane constant plus a compile-time tile offset (the tile loops are fully
 // unrolled: tile k of a wave is image row wave + 4k), row validity is wave-uniform (scalar branch), the padding columns
 // are never written (they stay zero from the initial clear), and global offsets are 32-bit from a per-strip scalar base.
 __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ ch, const half8* __restrict__ wfrag,
