@@ -38,7 +38,15 @@ struct ce_denoiser {
 
 namespace {
 
-constexpr int DN_T = 32;                  // output subcarriers per strip
+#ifndef DN_MIN_WAVES
+#define DN_MIN_WAVES 3   // workgroups per CU the register allocator leaves room for (41 KB of LDS allow 3)
+#endif
+#ifndef DN_T_ROWS
+#define DN_T_ROWS 32
+#endif
+constexpr int DN_T = DN_T_ROWS;           // output subcarriers per strip (a multiple of 16: each wave owns blocks of 4 rows)
+constexpr int DN_NB3 = DN_T / 16;         // layer-3 blocks per wave
+static_assert(DN_T % 16 == 0, "strip height");
 constexpr int DN_NT = 256, DN_COLS = 16, DN_C = CE_DN_CHANNELS;
 constexpr int X0_PIX = (DN_T + 6) * DN_COLS + 2;  // + one pad pixel in front and behind
 constexpr int X1_PIX = (DN_T + 4) * DN_COLS + 2;
@@ -67,7 +75,7 @@ __device__ __forceinline__ half4 relu_h4(f32x4 acc) {
 // cores or the LDS, unless the per-tile bookkeeping is scalar or constant: every LDS address below is a per-lane constant plus a compile-time tile offset (the tile loops are fully
 // unrolled: tile k of a wave is image row wave + 4k), row validity is wave-uniform (scalar branch), the padding columns
 // are never written (they stay zero from the initial clear), and global offsets are 32-bit from a per-strip scalar base.
-__global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ ch, const half8* __restrict__ wfrag,
+__global__ __launch_bounds__(DN_NT, DN_MIN_WAVES) void ce_denoise_kernel(float2* __restrict__ ch, const half8* __restrict__ wfrag,
                                                             const float* __restrict__ bias, int n_sc, int L) {
   __shared__ __attribute__((aligned(16))) half2v x0[2][X0_PIX];
   __shared__ __attribute__((aligned(16))) _Float16 x1[X1_PIX * DN_C];
@@ -172,9 +180,9 @@ __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ 
     // The next strip's input rows overlap this strip's output rows: request them (and this strip's float32 residuals)
     // now, before layer 3 overwrites them; they are consumed after layer 1 / in layer 3.
     if (s + 1 < n_strips) stage_load(r0 + DN_T);
-    float2 hres[2][2];  // [block][row 2g + e]: float32 residuals of this lane's four outputs
+    float2 hres[DN_NB3][2];  // [block][row 2g + e]: float32 residuals of this lane's outputs
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < DN_NB3; ++b)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         hres[b][e] = make_float2(0.f, 0.f);
@@ -248,22 +256,22 @@ __global__ __launch_bounds__(DN_NT) void ce_denoise_kernel(float2* __restrict__ 
       }
     }
     __syncthreads();
-    // ---- layer 3 + residual: x2 -> grid rows r0 .. r0+T-1, two blocks of 4 rows per wave (rows 4 wave + 16 b ..)
+    // ---- layer 3 + residual: x2 -> grid rows r0 .. r0+T-1, T/16 blocks of 4 rows per wave (rows 4 wave + 16 b ..)
     {
       const char* xin = reinterpret_cast<const char*>(x2);
       half8 fr[2][9];
 #pragma unroll
       for (int j = 0; j < 9; ++j) fr[0][j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (j / 3) * ROW_BYTES16);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (b == 0) {
+      for (int b = 0; b < DN_NB3; ++b) {
+        if (b + 1 < DN_NB3) {
 #pragma unroll
-          for (int j = 0; j < 9; ++j) fr[1][j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (16 + j / 3) * ROW_BYTES16);
+          for (int j = 0; j < 9; ++j) fr[(b + 1) & 1][j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (16 * (b + 1) + j / 3) * ROW_BYTES16);
         }
         asm volatile("" ::: "memory");
         f32x4 acc = b3;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[j], fr[b][j], acc, 0, 0, 0);
+        for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[j], fr[b & 1][j], acc, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
           if ((!(DN_ABLATE & 1) || acc[0] == 123.456f) && h_lane && r0 + h_row + 16 * b + e < n_sc)
