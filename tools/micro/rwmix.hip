@@ -1,0 +1,84 @@
+// Dev microbenchmark (GPU box): the memory system's bound for the estimator's ACCESS PATTERN with no estimation work --
+// per work item: read two 26 KB DM-RS rows (every other complex64, as the comb-2 pilots are) + 26 KB of pilots shared by 4
+// items, then write 366 912 contiguous bytes with 252 lanes of float4; one 256-thread workgroup per item, LDS padded so
+// that 3 or 4 workgroups fit a CU.  `dep`: the written value depends on the loaded data (as the estimate does) or not.
+// hipcc --offload-arch=gfx950 -O3 -o /tmp/rwmix tools/micro/rwmix.hip && /tmp/rwmix
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+constexpr int N_SC = 3276, N_SYM = 14, N_RE = 1638, ROW4 = 7, ACTIVE = 252;
+
+template <bool DEP, bool READ>
+__global__ __launch_bounds__(256) void rwmix(const float2* __restrict__ rx, const float2* __restrict__ pil, float4* __restrict__ out,
+                                             int n_ports, int xcd_map) {
+  extern __shared__ float red[];
+  const int tid = threadIdx.x;
+  int item = blockIdx.x;
+  if (xcd_map) {  // ports of a slot 8 workgroups apart (same XCD), as the estimator places them
+    const int per = 8 * n_ports, g = item / per, j = item - g * per;
+    item = (g * 8 + (j & 7)) * n_ports + (j >> 3);
+  }
+  const int slot = item / n_ports;
+  const float2* r = rx + (size_t)item * N_SC * N_SYM;   // [sym][sc] buffer of this item
+  float acc = 0.f;
+  if (READ) {
+    for (int k = tid; k < N_RE; k += 256) {
+      const float2 a = r[2 * N_SC + 2 * k], b = r[11 * N_SC + 2 * k];
+      const float2 p = pil[(size_t)slot * N_RE * 2 + k], q = pil[(size_t)slot * N_RE * 2 + N_RE + k];
+      acc += a.x * p.x + a.y * p.y + b.x * q.x + b.y * q.y;
+    }
+  }
+  float v = 1.f;
+  if (DEP) {  // block-wide dependence of every store on every load, like the estimate's
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    v = red[0];
+  } else if (READ) {
+    if (acc == 123.456f) v = 2.f;   // keeps the loads alive; stores may issue before they return
+  }
+  if (tid < ACTIVE) {
+    float4* o = out + (size_t)item * (N_SC * ROW4) + tid;
+    const float4 val = make_float4(v, v + 1.f, v + 2.f, (float)item);
+#pragma unroll 4
+    for (int s = tid / ROW4; s < N_SC; s += ACTIVE / ROW4) { *o = val; o += ACTIVE; }
+  }
+}
+
+template <typename F> double time_ms(F f, int iters) {
+  hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  f(); f();
+  CHECK(hipEventRecord(a));
+  for (int i = 0; i < iters; ++i) f();
+  CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+  float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters;
+}
+
+int main() {
+  const int n_slots = 8192, n_ports = 4, n_items = n_slots * n_ports;
+  float2 *rx, *pil; float4* out;
+  CHECK(hipMalloc(&rx, (size_t)n_items * N_SC * N_SYM * 8));
+  CHECK(hipMalloc(&pil, (size_t)n_slots * N_RE * 2 * 8));
+  CHECK(hipMalloc(&out, (size_t)n_items * N_SC * N_SYM * 8));
+  CHECK(hipMemset(rx, 0, (size_t)n_items * N_SC * N_SYM * 8));
+  CHECK(hipMemset(pil, 0, (size_t)n_slots * N_RE * 2 * 8));
+  const double alg = (double)n_slots * 1598688.0;
+  for (int wgs : {3, 4, 6}) {
+    const int lds = wgs == 3 ? 50 * 1024 : wgs == 4 ? 38 * 1024 : 24 * 1024;   // dynamic LDS that lets exactly `wgs` fit 160 KB
+    CHECK(hipFuncSetAttribute((const void*)rwmix<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipFuncSetAttribute((const void*)rwmix<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipFuncSetAttribute((const void*)rwmix<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    for (int xm : {1, 0}) {
+      double t = time_ms([&] { rwmix<true, true><<<n_items, 256, lds>>>(rx, pil, out, n_ports, xm); }, 5);
+      printf("%d WG/CU xcd_map=%d read -> dependent write : %.3f ms  %.0f GB/s algorithmic\n", wgs, xm, t, alg / t / 1e6);
+      t = time_ms([&] { rwmix<false, true><<<n_items, 256, lds>>>(rx, pil, out, n_ports, xm); }, 5);
+      printf("%d WG/CU xcd_map=%d read || independent write: %.3f ms  %.0f GB/s algorithmic\n", wgs, xm, t, alg / t / 1e6);
+    }
+    double t = time_ms([&] { rwmix<false, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, 1); }, 5);
+    printf("%d WG/CU write only                           : %.3f ms  %.0f GB/s of stores\n", wgs, t, (double)n_items * 366912 / t / 1e6);
+  }
+  return 0;
+}
