@@ -292,11 +292,12 @@ def estimate(received_rg: torch.Tensor, pilots: torch.Tensor, beta_dmrs, hop1, h
     return res
 
 
-def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1, hop2, config
+def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1, hop2, config, *, interp: str = "linear"
                           ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Drop-in for the reference's single-slot, single-port entry point (T:745-772): same
     arguments, same 6-tuple (grid in the input's complex dtype and device, 0-d float64 scalars,
-    shape-(0,) ``cfo`` when not estimated).  The arithmetic runs on the current ROCm device."""
+    shape-(0,) ``cfo`` when not estimated).  The arithmetic runs on the current ROCm device.
+    ``interp="cnn"`` is ``src/ce_dl_cnn.py``'s entry point of the same signature (C:802)."""
     received_rg = torch.as_tensor(received_rg)
     pilots = torch.as_tensor(pilots)
     if not torch.is_complex(received_rg):
@@ -306,7 +307,7 @@ def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1, hop2, config
     in_dev, in_dtype = received_rg.device, received_rg.dtype
     dev = in_dev if in_dev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
     rg = received_rg.to(device=dev, dtype=torch.complex64)[None, None]
-    res = estimate(rg, pilots.to(dev), beta_dmrs, hop1, hop2, config)
+    res = estimate(rg, pilots.to(dev), beta_dmrs, hop1, hop2, config, interp=interp)
     ch = res[0][0, 0].to(device=in_dev, dtype=in_dtype)
     scal = [t.reshape(()).to(in_dev) if t.numel() else t.to(in_dev) for t in res[1:]]
     return (ch, *scal)

@@ -264,3 +264,21 @@ def test_launch_is_hip_graph_capturable():
     torch.cuda.synchronize()
     for a, b in zip(replayed, direct):
         assert torch.equal(a, b)
+
+
+def test_ce_dl_cnn_alias_module_matches_its_reference_fixture():
+    """`compat/ce_dl_cnn.py`: the reference's third module name, single-slot signature (C:802), CPU tensors in."""
+    import importlib
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT / "compat"))
+    try:
+        sys.modules.pop("ce_dl_cnn", None)
+        m = importlib.import_module("ce_dl_cnn")
+        fx = load_fixture("cnn_alpha05_3prb")
+        out = m.srs_channel_estimator(torch.from_numpy(fx.grids[0]), torch.from_numpy(fx.pilots), fx.beta, fx.hop1, fx.hop2, fx.config)
+        got = [float(x) for x in out[1:]]
+        check_outputs(out[0].numpy(), got, fx.ref_ch_est[0], fx.ref_scalars[0], TOL_CH, TOL_SC, "ce_dl_cnn alias")
+    finally:
+        sys.path.remove(str(ROOT / "compat"))
+        sys.modules.pop("ce_dl_cnn", None)

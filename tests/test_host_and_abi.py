@@ -170,14 +170,17 @@ def test_compat_alias_modules_expose_the_reference_names():
     import sys
     sys.path.insert(0, str(ROOT / "compat"))
     try:
-        for mod in ("ce_rule_tensorized", "srs_estimator_torch"):
+        for mod in ("ce_rule_tensorized", "srs_estimator_torch", "ce_rule_baseline", "ce_dl_cnn"):
             sys.modules.pop(mod, None)
             m = importlib.import_module(mod)
-            assert m.srs_channel_estimator is E.srs_channel_estimator
+            if mod == "ce_dl_cnn":      # the reference's third variant: same signature, in-painting interpolation
+                assert m.srs_channel_estimator.func is E.srs_channel_estimator and m.srs_channel_estimator.keywords == {"interp": "cnn"}
+            else:
+                assert m.srs_channel_estimator is E.srs_channel_estimator
             hop = m.HopConfig(DMRSsymbols=[1] + [0] * 13, DMRSREmask=[[1]] * 12, PRBstart=0, nPRBs=1, maskPRBs=[1], startSymbol=0, nAllocatedSymbols=14)
             cfg = m.EstimatorConfig(scs=15e3, CyclicPrefixDurations=[0.0] * 14)
             assert cfg.Smoothing == "filter" and cfg.CFOCompensate is True and hop.nPRBs == 1      # defaults of T:24-29
     finally:
         sys.path.remove(str(ROOT / "compat"))
-        for mod in ("ce_rule_tensorized", "srs_estimator_torch"):
+        for mod in ("ce_rule_tensorized", "srs_estimator_torch", "ce_rule_baseline", "ce_dl_cnn"):
             sys.modules.pop(mod, None)
