@@ -85,7 +85,10 @@ def compare_at_entries(estimate: np.ndarray, entries: np.ndarray) -> Tuple[float
 # `port_channel_estimator_fd_smoothing_strategy::X, <cfo flag>, <grid PRBs>`, per-layer pattern blocks holding a
 # 14-entry DM-RS symbol mask, one or two grid-wide PRB masks, an optional hop symbol and a 12-entry RE pattern, and
 # the three `"...N.dat"` file names) -- parsed here structurally (nested brace lists) rather than by position, so
-# either field order inside a pattern block is accepted.  Unverified against a real file: "format unpinned".
+# either field order inside a pattern block is accepted.  No real header exists here ("format unpinned" against srsRAN's
+# generator), but the part the harness reads is pinned: the reference's own validate_all.py (its parser, its runner and
+# its estimator, on CPU in the build container) reads the synthetic sets of tests/test_vector_header.py -- one hop, two
+# hops, two layers -- and reports <= 1.2e-7 against the expected outputs this module's conventions produced.
 # ----------------------------------------------------------------------------------------------------------------
 import itertools
 import re
@@ -184,7 +187,10 @@ def parse_test_data_header(text: str) -> List[VectorCase]:
         _, first_sym, n_syms = after("cyclic_prefix::", 2)
         smoothing, cfo_flag, grid_prbs = after("port_channel_estimator_fd_smoothing_strategy::", 2)
         i_smooth = next(k for k, t in enumerate(flat) if str(t).startswith("port_channel_estimator_fd_smoothing_strategy::"))
-        betas = [t for t in flat[:i_smooth] if _NUM.match(t) and not re.fullmatch(r"[-+]?\d+", t)]   # the scaling is the only real-valued field of the configuration
+        # the scaling: the harness takes the last number in front of the smoothing enum (validate_all.py:231-235); prefer
+        # a real-valued literal, the configuration's only one, so that integer lists next to it cannot be mistaken for it
+        nums = [t for t in flat[:i_smooth] if _NUM.match(t)]
+        betas = [t for t in nums if not re.fullmatch(r"[-+]?\d+", t)] or nums[-1:]
         strings = [t.strip('"') for t in flat if t.startswith('"')]
         files = {}
         for s in strings:

@@ -23,19 +23,25 @@ def _pattern(symbols, masks, hop_symbol, re_pattern, srs_order):
     return "{" + ", ".join(parts) + "}"
 
 
-def _header_case(idx, scs_khz, start, n_alloc, layer_patterns, beta, smoothing, cfo, grid_prbs, scalars):
-    cfg = (f"{{subcarrier_spacing::kHz{scs_khz}, cyclic_prefix::NORMAL, {start}, {n_alloc}, {{{', '.join(layer_patterns)}}}, "
-           f"{beta}, {{0}}, port_channel_estimator_fd_smoothing_strategy::{smoothing}, {'true' if cfo else 'false'}}}")
+def _header_case(idx, scs_khz, start, n_alloc, layer_patterns, beta, smoothing, cfo, grid_prbs, scalars, flat):
+    """One initializer block.  What the reference's harness extracts pins part of the real layout: the scaling is the last
+    number in front of the smoothing enum (validate_all.py:231-235) and `<cfo flag>, <grid PRBs>` follow the enum
+    (validate_all.py:224-229, no brace in between: `flat`); the braced variant is what a nested configuration struct would
+    print.  The parser accepts both; the harness's own parser was run on the flat sets in the build container and agrees
+    field for field (52-PRB grids only: it hard-codes that mask length, validate_all.py:171)."""
+    close_cfg, close_case = ("", "}") if flat else ("}", "")
+    cfg = (f"{{subcarrier_spacing::kHz{scs_khz}, cyclic_prefix::NORMAL, {start}, {n_alloc}, {{{', '.join(layer_patterns)}}}, {{0}}, "
+           f"{beta}, port_channel_estimator_fd_smoothing_strategy::{smoothing}, {'true' if cfo else 'false'}{close_cfg}")
     files = ", ".join(f'{{"test_data/port_channel_estimator_test_{k}{idx}.dat"}}' for k in ("input_rg", "pilots", "output_ch_est"))
-    return f"  {{{cfg}, {grid_prbs}, {', '.join(f'{v:.6g}' for v in scalars)}, {files}}},"
+    return f"  {{{cfg}, {grid_prbs}{close_case}, {', '.join(f'{v:.6g}' for v in scalars)}, {files}}},"
 
 
 SETS = [
     # idx, grid, scs, smoothing, cfo, layers, hops [(dmrs symbols, prb_start, n_prbs)], hop symbol, re patterns per layer, pilot order, srs field order
-    dict(idx=0, grid=52, scs=15, smoothing="filter", cfo=True, dmrs=[0, 4, 8, 12], bands=[(40, 3)], hop=None, re=[S.TYPE1_CDM0], order="sym-re-layer", srs=True),
-    dict(idx=4, grid=52, scs=15, smoothing="filter", cfo=True, dmrs=[0, 4, 8, 12], bands=[(3, 3), (28, 3)], hop=7, re=[S.TYPE1_CDM0], order="sym-re-layer", srs=True),
-    dict(idx=8, grid=52, scs=30, smoothing="mean", cfo=False, dmrs=[2, 11], bands=[(10, 25)], hop=None, re=[S.TYPE1_CDM0, S.TYPE1_CDM0], order="layer-sym-re", srs=False),
-    dict(idx=17, grid=106, scs=30, smoothing="none", cfo=True, dmrs=[2, 7, 11], bands=[(0, 106)], hop=None, re=[S.TYPE1_CDM0, S.TYPE1_CDM0, S.TYPE1_CDM1], order="re-sym-layer", srs=True),
+    dict(idx=0, grid=52, scs=15, smoothing="filter", cfo=True, dmrs=[0, 4, 8, 12], bands=[(40, 3)], hop=None, re=[S.TYPE1_CDM0], order="sym-re-layer", srs=True, flat=True),
+    dict(idx=4, grid=52, scs=15, smoothing="filter", cfo=True, dmrs=[0, 4, 8, 12], bands=[(3, 3), (28, 3)], hop=7, re=[S.TYPE1_CDM0], order="sym-re-layer", srs=False, flat=True),   # both PRB masks in front of the hop symbol: the only order the harness reads as two hops (validate_all.py:166-176)
+    dict(idx=8, grid=52, scs=30, smoothing="mean", cfo=False, dmrs=[2, 11], bands=[(10, 25)], hop=None, re=[S.TYPE1_CDM0, S.TYPE1_CDM0], order="layer-sym-re", srs=False, flat=False),
+    dict(idx=17, grid=106, scs=30, smoothing="none", cfo=True, dmrs=[2, 7, 11], bands=[(0, 106)], hop=None, re=[S.TYPE1_CDM0, S.TYPE1_CDM0, S.TYPE1_CDM1], order="re-sym-layer", srs=True, flat=False),
 ]
 
 
@@ -98,7 +104,7 @@ def _build(tmp_path):
         sc, sym, lay = np.nonzero(ch)
         V.write_entries(name("output_ch_est"), sym, lay, sc, ch[sc, sym, lay])
         scalars = [ref[1], ref[2], ref[3], 10 * np.log10(ref[2] / ref[1]), ref[4] * 1e6, 0.0 if ref[5] is None else ref[5]]
-        lines.append(_header_case(spec["idx"], spec["scs"], 0, 14, patterns, 1.4125, spec["smoothing"], spec["cfo"], spec["grid"], scalars))
+        lines.append(_header_case(spec["idx"], spec["scs"], 0, 14, patterns, 1.4125, spec["smoothing"], spec["cfo"], spec["grid"], scalars, spec["flat"]))
         truth[spec["idx"]] = dict(h1=h1, h2=h2, ref=ref, n_layers=len(spec["re"]), spec=spec)
     header = ("#pragma once\n// generated by the test\n#include \"some/header.h\"\nnamespace srsran {\nstruct test_case_t { int a; /* { not a brace } */ };\n"
               "static const std::vector<test_case_t> port_channel_estimator_test_data = {\n    // clang-format off\n"
