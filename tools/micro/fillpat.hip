@@ -43,6 +43,13 @@ __global__ void patG(float4* p, size_t n4) {
   const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+// H: pattern A with the occupancy limited through dynamic LDS (fewer concurrent item streams per CU)
+__global__ void patH(float4* p) {
+  extern __shared__ float pad[];
+  float4* q = p + blockIdx.x * CH4; const float4 v = make_float4(1.f, 2.f, 3.f, (float)blockIdx.x);
+  if (threadIdx.x == 999) pad[0] = 1.f;
+  if (threadIdx.x < 252) for (size_t i = threadIdx.x; i < CH4; i += 252) q[i] = v;
+}
 template <typename F> double time_ms(F f, int iters) {
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
   f(); f(); CHECK(hipEventRecord(a)); for (int i = 0; i < iters; ++i) f(); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
@@ -58,6 +65,10 @@ int main() {
     t = time_ms([&] { CHECK(hipMemsetD32Async((hipDeviceptr_t)p, 0x3F8CCCCD, n * CH4 * 4, 0)); }, 5); printf("hipMemsetD32 of 1.1f             %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
     for (int b : {128, 256, 512, 768, 1024, 2048}) {
       t = time_ms([&] { patG<<<b, 256>>>(p, n * CH4); }, 5); printf("G grid-stride, %4d workgroups     %.3f ms %.0f GB/s\n", b, t, gb / t * 1e3);
+    }
+    for (int kb : {150, 75, 50, 38, 24, 12}) {
+      CHECK(hipFuncSetAttribute((const void*)patH, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024));
+      t = time_ms([&] { patH<<<n, 256, kb * 1024>>>(p); }, 5); printf("H pattern A, %3d KB LDS (%d WG/CU)  %.3f ms %.0f GB/s\n", kb, 160 / kb > 8 ? 8 : 160 / kb, t, gb / t * 1e3);
     }
     t = time_ms([&] { patB<<<n, 256>>>(p); }, 5); printf("B wave-contiguous quarters       %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
     t = time_ms([&] { patC<<<n, 256>>>(p); }, 5); printf("C 64 B per lane                  %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
