@@ -47,6 +47,70 @@ __global__ __launch_bounds__(256) void rwmix(const float2* __restrict__ rx, cons
   }
 }
 
+// Upper bound of a "sweep writer" redesign: persistent workgroups; each alternates between reading + reducing one item's
+// pilots and writing one item's worth of output in 4 KB chunks handed out by a global ticket counter, so that the chip's
+// stores advance through the output in address order while the reads stay interleaved as in the fused kernel.  (A real
+// design would take the written values from a cache-resident workspace and needs generation barriers: not modelled.)
+__global__ __launch_bounds__(256) void sweepmix(const float2* __restrict__ rx, const float2* __restrict__ pil, float4* __restrict__ out,
+                                                int n_items, int n_ports, unsigned long long* ticket, unsigned long long n_chunks, int chunk4) {
+  __shared__ float red[256];
+  __shared__ unsigned long long first;
+  const int tid = threadIdx.x;
+  const int per_item = (N_SC * ROW4 + chunk4 - 1) / chunk4;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int slot = item / n_ports;
+    const float2* r = rx + (size_t)item * N_SC * N_SYM;
+    float acc = 0.f;
+    for (int k = tid; k < N_RE; k += 256) {
+      const float2 a = r[2 * N_SC + 2 * k], b = r[11 * N_SC + 2 * k];
+      const float2 p = pil[(size_t)slot * N_RE * 2 + k], q = pil[(size_t)slot * N_RE * 2 + N_RE + k];
+      acc += a.x * p.x + a.y * p.y + b.x * q.x + b.y * q.y;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const float v = red[0];
+    if (tid == 0) first = atomicAdd(ticket, (unsigned long long)per_item);   // this workgroup's run of consecutive chunks
+    __syncthreads();
+    const unsigned long long c0 = first;
+    const float4 val = make_float4(v, v + 1.f, v + 2.f, (float)item);
+    for (int c = 0; c < per_item; ++c) {
+      const unsigned long long ch = c0 + c;
+      if (ch < n_chunks) for (int i = tid; i < chunk4; i += 256) out[ch * chunk4 + i] = val;
+    }
+    __syncthreads();
+  }
+}
+// the same with the tickets taken one 4 KB chunk at a time (finest interleaving of the chip's stores)
+__global__ __launch_bounds__(256) void sweepmix1(const float2* __restrict__ rx, const float2* __restrict__ pil, float4* __restrict__ out,
+                                                 int n_items, int n_ports, unsigned long long* ticket, unsigned long long n_chunks, int chunk4) {
+  __shared__ float red[256];
+  __shared__ unsigned long long first;
+  const int tid = threadIdx.x;
+  const int per_item = (N_SC * ROW4 + chunk4 - 1) / chunk4;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int slot = item / n_ports;
+    const float2* r = rx + (size_t)item * N_SC * N_SYM;
+    float acc = 0.f;
+    for (int k = tid; k < N_RE; k += 256) {
+      const float2 a = r[2 * N_SC + 2 * k], b = r[11 * N_SC + 2 * k];
+      const float2 p = pil[(size_t)slot * N_RE * 2 + k], q = pil[(size_t)slot * N_RE * 2 + N_RE + k];
+      acc += a.x * p.x + a.y * p.y + b.x * q.x + b.y * q.y;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const float4 val = make_float4(red[0], 1.f, 2.f, (float)item);
+    for (int c = 0; c < per_item; ++c) {
+      __syncthreads();
+      if (tid == 0) first = atomicAdd(ticket, 1ull);
+      __syncthreads();
+      const unsigned long long ch = first;
+      if (ch < n_chunks) for (int i = tid; i < chunk4; i += 256) out[ch * chunk4 + i] = val;
+    }
+    __syncthreads();
+  }
+}
 template <typename F> double time_ms(F f, int iters) {
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
   f(); f();
@@ -79,6 +143,16 @@ int main() {
     }
     double t = time_ms([&] { rwmix<false, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, 1); }, 5);
     printf("%d WG/CU write only                           : %.3f ms  %.0f GB/s of stores\n", wgs, t, (double)n_items * 366912 / t / 1e6);
+  }
+  unsigned long long* ticket; CHECK(hipMalloc(&ticket, 8));
+  for (int chunk4 : {256, 1024}) {   // 4 KB and 16 KB chunks
+    const unsigned long long n_chunks = ((unsigned long long)n_items * N_SC * ROW4) / chunk4;
+    for (int wgs : {3, 4}) {
+      double t = time_ms([&] { CHECK(hipMemsetAsync(ticket, 0, 8, 0)); sweepmix<<<256 * wgs, 256>>>(rx, pil, out, n_items, n_ports, ticket, n_chunks, chunk4); }, 5);
+      printf("sweep writer bound, %2d KB chunks, item-sized ticket runs, %d WG/CU: %.3f ms  %.0f GB/s algorithmic\n", chunk4 / 64, wgs, t, alg / t / 1e6);
+      t = time_ms([&] { CHECK(hipMemsetAsync(ticket, 0, 8, 0)); sweepmix1<<<256 * wgs, 256>>>(rx, pil, out, n_items, n_ports, ticket, n_chunks, chunk4); }, 5);
+      printf("sweep writer bound, %2d KB chunks, one ticket per chunk,    %d WG/CU: %.3f ms  %.0f GB/s algorithmic\n", chunk4 / 64, wgs, t, alg / t / 1e6);
+    }
   }
   return 0;
 }
