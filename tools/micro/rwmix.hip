@@ -111,6 +111,51 @@ __global__ __launch_bounds__(256) void sweepmix1(const float2* __restrict__ rx, 
     __syncthreads();
   }
 }
+// Lock-step generations: all resident workgroups read + reduce one item each, meet at a grid barrier, then write the
+// generation's contiguous output region grid-stride (chunk j, j + G, j + 2G, ... of 4 KB): a static sweep, no tickets.
+// The next generation's reads overlap the tail of this one's stores.  (Written values would come from a cache-resident
+// workspace in a real design: not modelled.)
+__global__ __launch_bounds__(256) void lockstep(const float2* __restrict__ rx, const float2* __restrict__ pil, float4* __restrict__ out,
+                                                int n_items, int n_ports, unsigned* bar) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x, G = gridDim.x;
+  const size_t item4 = (size_t)N_SC * ROW4;
+  unsigned gen = 0;
+  for (int base = 0; base < n_items; base += G, ++gen) {
+    const int item = base + blockIdx.x;
+    float v = 0.f;
+    if (item < n_items) {
+      const int slot = item / n_ports;
+      const float2* r = rx + (size_t)item * N_SC * N_SYM;
+      float acc = 0.f;
+      for (int k = tid; k < N_RE; k += 256) {
+        const float2 a = r[2 * N_SC + 2 * k], b = r[11 * N_SC + 2 * k];
+        const float2 p = pil[(size_t)slot * N_RE * 2 + k], q = pil[(size_t)slot * N_RE * 2 + N_RE + k];
+        acc += a.x * p.x + a.y * p.y + b.x * q.x + b.y * q.y;
+      }
+      red[tid] = acc;
+      __syncthreads();
+      for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+      v = red[0];
+    }
+    // grid barrier: every resident workgroup arrives once per generation
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      atomicAdd(bar, 1u);
+      while (atomicAdd(bar, 0u) < (gen + 1) * (unsigned)G) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    const int n_here = min(G, n_items - base);
+    const size_t region4 = (size_t)n_here * item4;
+    float4* o = out + (size_t)base * item4;
+    const float4 val = make_float4(v, 1.f, 2.f, (float)item);
+    for (size_t c = (size_t)blockIdx.x * 256; c < region4; c += (size_t)G * 256) {
+      const size_t i = c + tid;
+      if (i < region4) o[i] = val;
+    }
+  }
+}
 template <typename F> double time_ms(F f, int iters) {
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
   f(); f();
@@ -143,6 +188,11 @@ int main() {
     }
     double t = time_ms([&] { rwmix<false, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, 1); }, 5);
     printf("%d WG/CU write only                           : %.3f ms  %.0f GB/s of stores\n", wgs, t, (double)n_items * 366912 / t / 1e6);
+  }
+  unsigned* bar; CHECK(hipMalloc(&bar, 4));
+  for (int wgs : {1, 2, 3}) {
+    double t = time_ms([&] { CHECK(hipMemsetAsync(bar, 0, 4, 0)); lockstep<<<256 * wgs, 256>>>(rx, pil, out, n_items, n_ports, bar); }, 5);
+    printf("lock-step generations, static sweep, %d WG/CU: %.3f ms  %.0f GB/s algorithmic\n", wgs, t, alg / t / 1e6);
   }
   unsigned long long* ticket; CHECK(hipMalloc(&ticket, 8));
   for (int chunk4 : {256, 1024}) {   // 4 KB and 16 KB chunks
