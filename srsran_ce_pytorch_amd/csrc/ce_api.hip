@@ -379,14 +379,35 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     // absorbs the 1/(1+1e-12) factor of the remaining max(6, n/8) - 2), and the two low-pass passes then give
     // (P[k-1] + 15 P[k] + 15 P[k+1] + P[k+2]) / 32 with reflected pilot indices at the band edges: the writer evaluates
     // that straight from P, no whole-band staging (measured against the real ce_dl_cnn.py fixtures like the general form).
+    // Any other mask: the iteration x <- (x[i-1] + 2 x[i] + x[i+1]) / 4 on the unknown REs converges to the straight line
+    // between the neighbouring pilots (flat beyond the first / last one: reflect padding), with factor
+    // cos^2(pi / (2 (g + 1))) per iteration for a run of g unknowns (an edge run of e counts as 2 e - 1, mirrored).  When
+    // max(6, n / 8) iterations bring that below 1e-6 (20x inside the parity tolerance) the reference sits on the fixed point, and
+    // in-painting + low-pass is the 5-tap binomial [1 4 6 4 1] / 16 over the linear fill of T:311-338, pilots restored
+    // (mode 2).  Shorter bands, or sparser masks, depend on the exact iteration count and are iterated as before.
     P.cnn_comb2 = 0;
     if (d->interp == CE_INTERP_CNN && !getenv("CE_CNN_GENERAL")) {  // env: tuning / A-B knob
-      P.cnn_comb2 = 1;
+      bool comb2 = true, converges = true;
       for (int h = 0; h < d->n_hops; ++h)
         for (int c = 0; c < n_cdm; ++c) {
           const unsigned m12 = (P.hop[h].mask12 >> (16 * c)) & 0xFFFu;
-          if (m12 != 0x555u && m12 != 0xAAAu) P.cnn_comb2 = 0;
+          if (m12 != 0x555u && m12 != 0xAAAu) comb2 = false;
+          if (m12 == 0xFFFu) { converges = false; continue; }   // every RE a pilot: low-pass only (C:487-488), general form
+          int first = 0, last = 11, g = 0, run = 0;
+          while (!((m12 >> first) & 1u)) ++first;
+          while (!((m12 >> last) & 1u)) --last;
+          for (int r = first; r <= last; ++r) {
+            if ((m12 >> r) & 1u) run = 0; else if (++run > g) g = run;
+          }
+          const int wrap = (11 - last) + first;                   // run across a PRB boundary
+          if (P.hop[h].n_prbs > 1 && wrap > g) g = wrap;
+          if (2 * first - 1 > g) g = 2 * first - 1;               // band edges, mirrored
+          if (2 * (11 - last) - 1 > g) g = 2 * (11 - last) - 1;
+          const int n_it = P.hop[h].n_sc_hop / 8 > 6 ? P.hop[h].n_sc_hop / 8 : 6;
+          const double cs = cos(M_PI / (2.0 * (g + 1)));
+          if (g > 0 && log(1e-6) / log(cs * cs) > (double)n_it) converges = false;
         }
+      P.cnn_comb2 = comb2 ? 1 : converges ? 2 : 0;
     }
     if (d->interp == CE_INTERP_CNN && !P.cnn_comb2) {
       // whole-band H rows for every (hop, layer) + a second x buffer + two mask byte arrays

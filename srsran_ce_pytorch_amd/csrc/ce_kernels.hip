@@ -1207,6 +1207,31 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
     return make_float2(((a.x + d2.x) + 15.f * (b.x + c.x)) * (1.f / 32.f), ((a.y + d2.y) + 15.f * (b.y + c.y)) * (1.f / 32.f));
   };
 
+  // the same for any mask whose in-painting reaches its fixed point within the reference's iteration count (ce_api.hip:
+  // cnn_comb2 == 2): 5-tap binomial (two [1 2 1] / 4 passes, reflect padding C:433-451) over the linear fill, pilots restored
+  auto cnnfp_at = [&](int h, int l, int p) -> float2 {
+    const CeDevHop& lh = lp->hop[h];
+    const int n = lh.n_sc_hop;
+    const int q12 = p / 12, r12 = p - 12 * q12;
+    if ((lh.mask12 >> (16 * (l >> 1) + r12)) & 1u) return interp_at(h, l, p);   // a pilot RE keeps its value (C:507-508)
+    auto rf = [&](int i) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); };
+    // y = lp(lp(x)), each pass with its own reflect padding: y[p] = sum_d w_d lp1(rf(p + d)), lp1(i) = sum_e w_e x(rf(i + e))
+    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+      const int i = rf(p + d);
+      const float wd = d == 0 ? 0.5f : 0.25f;
+#pragma unroll
+      for (int e = -1; e <= 1; ++e) {
+        const float2 x = interp_at(h, l, rf(i + e));
+        const float w = wd * (e == 0 ? 0.5f : 0.25f);
+        acc.x += w * x.x;
+        acc.y += w * x.y;
+      }
+    }
+    return acc;
+  };
+
   if (CE_ABLATE & 8) {
   } else if (n_sym == CE_MAX_SYMBOLS && !lp->sym_overlap) {
     // Fast writer (hop of an element decided by its symbol alone).  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
@@ -1278,7 +1303,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
             const int h = hl / L, l = hl - h * L;
             const int p = c0 + s - lp->hop[h].sc0;
             float2 v = make_float2(0.f, 0.f);
-            if (p >= 0 && p < lp->hop[h].n_sc_hop) v = lp->interp == CE_INTERP_CNN ? cnn2_at(h, l, p) : interp_at(h, l, p);
+            if (p >= 0 && p < lp->hop[h].n_sc_hop)
+              v = lp->interp != CE_INTERP_CNN ? interp_at(h, l, p) : lp->cnn_comb2 == 1 ? cnn2_at(h, l, p) : cnnfp_at(h, l, p);
             scratch[i] = v;
           }
         }

@@ -63,7 +63,7 @@ struct CeDevPlan {
   int32_t cnn_pong_off, cnn_m_off;    // byte offsets inside the scratch: second x buffer, two mask byte arrays
   int32_t cnn_n_max;                  // longest hop band (subcarriers)
   float cnn_alpha;                    // clamp(CNNSmoothingAlpha, 0, 1) (src/ce_dl_cnn.py:712-715)
-  int32_t cnn_comb2;                  // 1: every DM-RS mask is a comb-2 (1010.. / 0101..): the in-painting has a closed form
+  int32_t cnn_comb2;                  // in-painting in closed form: 1 comb-2 masks (1010.. / 0101..), 2 any mask whose gaps converge within n_iters; 0 iterate
   // extension: block LMMSE smoothing (CE_SMOOTH_MMSE)
   int32_t mmse_nb, mmse_nbp;          // blocks of CE_MMSE_BLOCK pilots, padded to a multiple of 16 (MFMA N tiles)
   double cnn_rcp[5];                  // 1 / (code/4 + 1e-12), code = m[i-1] + 2 m[i] + m[i+1] (src/ce_dl_cnn.py:498-501)

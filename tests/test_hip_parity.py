@@ -282,3 +282,22 @@ def test_ce_dl_cnn_alias_module_matches_its_reference_fixture():
     finally:
         sys.path.remove(str(ROOT / "compat"))
         sys.modules.pop("ce_dl_cnn", None)
+
+
+@pytest.mark.parametrize("mask,layers,smoothing", [("type2", 2, "filter"), ("every4th", 1, "none"), ("irregular", 1, "mean"), ("type2_pair", 3, "filter")])
+def test_hip_cnn_closed_form_for_converged_masks(mask, layers, smoothing):
+    """Wide hops (273 PRB: max(6, n/8) = 409 iterations) let the reference's in-painting reach its fixed point for runs
+    of up to 6 unknown REs; the kernel then evaluates binomial-over-linear-fill instead of iterating (ce_api.hip:
+    cnn_comb2 = 2).  Checked against the oracle, which iterates all 409 times like ce_dl_cnn.py."""
+    masks = {"type2": [S.TYPE2_CDM0], "every4th": [[1, 0, 0, 0] * 3], "irregular": [[1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0]],
+             "type2_pair": [S.TYPE2_CDM0, S.TYPE2_CDM1]}[mask]
+    case = S.case_spec(f"cnnfp_{mask}", 273, [S.hop_spec([2, 11], 3, 268, re_masks=masks)], n_layers=layers, smoothing=smoothing, seed=601)
+    b = S.build_case(case, 2)
+    b.config.CNNSmoothingAlpha = 0.3 if smoothing == "filter" else 0.0
+    view = E.derive_host(b.hop1, b.hop2, b.config, b.beta, layers, 273, 14, interp="cnn")
+    assert view.scratch_bytes < 40000                                    # no whole-band staging: the closed form was chosen
+    ch, sc = _run_items(b, b.grids, "sym_major", interp="cnn")
+    for it in range(2):
+        ref = O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp="cnn")
+        got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], sc[4][it]]
+        check_outputs(ch[it], got, ref[0], list(ref[1:]), TOL_CH, TOL_SC, f"cnnfp_{mask}[{it}]")

@@ -31,7 +31,7 @@ def draw(rng, max_grid):
     masks = [SINGLE[rng.integers(len(SINGLE))]] if layers <= 2 else PAIRS[rng.integers(len(PAIRS))]
     n_hops = int(rng.choice([1, 1, 2]))
     n_prbs = int(rng.integers(1, grid + 1)) if rng.random() < 0.3 else int(rng.integers(1, min(grid, 12) + 1))
-    interp = "cnn" if (rng.random() < 0.15 and grid <= 52) else "linear"
+    interp = "cnn" if rng.random() < (0.15 if grid <= 52 else 0.05) else "linear"   # wide CNN cases: closed-form writer for converged masks
     hops = []
     style = rng.choice(["split", "full", "partial"]) if n_hops == 2 and interp == "linear" else "split"
     for h in range(n_hops):
