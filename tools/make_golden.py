@@ -72,6 +72,8 @@ def golden_cases():
         # comb-2 masks on odd REs / in two CDM groups / on a single PRB: the closed-form writer's reflected band edges
         (CS("cnn_comb2_odd_3prb", 52, [H([2, 11], 9, 3, re_masks=[S.TYPE1_CDM1])], smoothing="none", seed=25), "C", 2),   # (>= 18 pilots: with <= 12 the TA peak is flat to float32 rounding)
         (dict(CS("cnn_layers4_comb2", 52, [H([2, 7, 11], 20, 7, re_masks=BOTH)], n_layers=4, seed=26), cnn_alpha=0.25), "C", 1),
+        # a wide type-2 hop: 409 iterations reach the fixed point, the HIP writer takes the closed form (binomial over linear fill)
+        (dict(CS("cnn_type2_273", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])], n_layers=2, seed=28), cnn_alpha=0.2), "C", 1),
         (CS("cnn_comb2_odd_2hop", 52, [H([3], 0, 5, 0, 7, [S.TYPE1_CDM1]), H([10], 47, 5, 7, 7, [S.TYPE1_CDM1])], smoothing="mean", seed=27), "C", 1),
     ]
     return cases
