@@ -63,6 +63,11 @@ def golden_cases():
         # hops carry the slot's symbol range) and a partial overlap in symbols AND PRBs (hop 2 overwrites, T:872-896)
         (CS("case4like_fullslot_hops", 52, [H([0, 4], 3, 3, 0, 14), H([8, 12], 28, 3, 0, 14)], scs=15e3, seed=30), "T", 2),
         (CS("hops_partial_overlap_L2", 52, [H([1, 4], 5, 8, 0, 10), H([8, 12], 9, 8, 6, 8)], n_layers=2, seed=31), "T", 1),
+        # one reference fixture per register-path tier of the kernel (wide 3 DM-RS, KPT=4 two hops, KPT=1 four DM-RS, KPT=2 three DM-RS)
+        (CS("dmrs3_273", 273, [H([2, 7, 11], 0, 273)], seed=32), "T", 1),
+        (CS("hop2_136prb_273", 273, [H([1, 5], 0, 136, 0, 7), H([8, 12], 137, 136, 7, 7)], seed=33), "T", 1),
+        (CS("dmrs4_20prb", 52, [H([2, 5, 8, 11], 7, 20)], seed=34), "T", 2),
+        (CS("dmrs3_70prb_106", 106, [H([2, 7, 11], 30, 70)], scs=15e3, smoothing="mean", seed=35), "T", 1),
         (CS("cnn_3prb", 52, [H([2, 11], 7, 3)], seed=20), "C", 2),
         (CS("cnn_type2_3prb", 52, [H([2, 11], 7, 3, re_masks=[S.TYPE2_CDM0])], seed=21), "C", 2),
         (CS("cnn_type2_2hop", 52, [H([2], 3, 3, 0, 7, [S.TYPE2_CDM0]), H([9], 28, 3, 7, 7, [S.TYPE2_CDM0])], seed=23), "C", 1),
