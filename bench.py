@@ -102,6 +102,44 @@ def cpu_baseline(case, n_ports, target_core_seconds=20.0, interp="linear", denoi
                        f"{per_item * 1e3:.2f} ms per slot-port on one core")
 
 
+def secondary_lines(E, S, plan, case, rx, pilots, out, n_slots, n_ports, dev, iters=5):
+    """The other parity-pinned workloads of BASELINE.json, a few launches each after the headline (N=1 only), so the
+    driver's record carries them: configs[1] (LS + linear interpolation, 1024 slots x 1 Rx), configs[4] as the reference
+    implements it (ce_dl_cnn in-painting), and the headline fed in the reference's own [sc][sym] grid layout (what the
+    drop-in shim receives; its algorithmic bytes are the same, its HBM traffic is the whole grid)."""
+    import torch
+
+    def timed(pl, rx_, pil_, out_, slots, ports, name, layout, workload_case):
+        ms = min(E.time_with_plan(pl, rx_, pil_, out_, 1, iters) for _ in range(2))
+        b = slots * (ports * pl.alg_bytes_per_item + pl.pilot_bytes_per_slot)
+        ach = b / (ms * 1e-3) / 1e9
+        return {"workload": name, "slots": slots, "rx_ports": ports, "smoothing": workload_case["smoothing"], "ms_per_step": ms,
+                "slots_per_s": slots / (ms * 1e-3), "rx_layout": layout,
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "alg_bytes_per_launch": b}}
+
+    res = []
+    # configs[1]: its own small resident batch
+    w1 = WORKLOADS["pusch273_1rx_none"]
+    c1 = S.bench_case(w1["smoothing"], 1, seed=4321)
+    h1, h2, cfg1 = S.numpy_hops(c1)
+    p1 = E.make_plan(h1, h2, cfg1, c1["beta"], 1, c1["n_prb_grid"], c1["n_sym"], dev)
+    rx1, pil1 = S.torch_inputs(c1, w1["slots"], w1["ports"], dev, seed=4321)
+    out1 = E.estimate_with_plan(p1, rx1, pil1)
+    res.append(timed(p1, rx1, pil1, out1, w1["slots"], w1["ports"], "pusch273_1rx_none", "[slot][port][sym][sc]", c1))
+    del rx1, pil1, out1
+    # configs[4] (reference form): same inputs and outputs as the headline, in-painting instead of linear interpolation
+    hh1, hh2, cfgh = S.numpy_hops(case)
+    pc = E.make_plan(hh1, hh2, cfgh, case["beta"], 1, case["n_prb_grid"], case["n_sym"], dev, "cnn")
+    res.append(timed(pc, rx, pilots, out, n_slots, n_ports, "pusch273_4rx_cnn", "[slot][port][sym][sc]", case))
+    # headline in the reference layout: dense [slot][port][sc][sym] grids
+    rx_ref = rx.contiguous()
+    res.append(timed(plan, rx_ref, pilots, out, n_slots, n_ports, "pusch273_4rx_filter", "[slot][port][sc][sym] (reference layout)", case))
+    del rx_ref
+    torch.cuda.synchronize()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +148,7 @@ def main():
     ap.add_argument("--workload", default="pusch273_4rx_filter", choices=sorted(WORKLOADS))
     ap.add_argument("--slots", type=int, default=None, help="slots per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads timed after the headline (N=1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,11 +231,11 @@ def main():
     # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the
     # MI355X guide prescribes for gfx950); collected once per round and committed under profiles/
     traffic, traffic_src = None, None
-    prof = ROOT / "profiles" / "round1_summary.json"
-    if prof.exists():
+    for prof in sorted((ROOT / "profiles").glob("round*_summary.json"), reverse=True):   # newest round first
         pj = json.loads(prof.read_text())
-        if pj.get("workload", "").startswith(args.workload) and n_slots == wl["slots"]:
-            traffic, traffic_src = pj["hbm_traffic_bytes_per_launch"], "profiles/round1_summary.json"
+        if pj.get("workload", "").startswith(args.workload) and n_slots == wl["slots"] and "hbm_traffic_bytes_per_launch" in pj:
+            traffic, traffic_src = pj["hbm_traffic_bytes_per_launch"], f"profiles/{prof.name}"
+            break
     line = {
         "metric": "slots/sec (273-PRB PUSCH, 4 Rx)" if n_ports == 4 else f"slots/sec (273-PRB PUSCH, {n_ports} Rx)",
         "value": value, "unit": "slots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,9 +246,11 @@ def main():
                    "global_slots": world * n_slots, "rx_layout": "[slot][port][sym][sc]", "parallelism": f"slot-shard x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "ce_estimate_kernel<1,1,2,7>", "kernel_ms": kernel_ms,
+                     "kernel": "ce_estimate_kernel<1,1,2,7,%d>" % (1 if wl["smoothing"] == "filter" else 3 if wl["smoothing"] == "mmse" else 0), "kernel_ms": kernel_ms,
                      "alg_bytes_per_slot": bytes_per_slot, "alg_bytes_per_launch": bytes_per_launch},
     }
+    if world == 1 and args.workload == "pusch273_4rx_filter" and not args.no_secondary:
+        line["secondary"] = secondary_lines(E, S, plan, case, rx, pilots, out, n_slots, n_ports, dev)
     if denoiser is not None:
         # dominant kernel of this workload: the denoiser; timed on its own (same stream, same resident batch)
         d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -15,7 +15,11 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = Path(os.environ.get("CE_HIP_LIB", CSRC / "libce_hip.so"))   # override: diagnostic builds (tools/)
-SOURCES = ["ce_api.hip", "ce_kernels.hip", "ce_denoise.hip"]
+# the estimation kernel template (ce_estimate_kernel.h) is instantiated in slices, one translation unit each, so the
+# units compile concurrently (ce_inst.inc)
+SOURCES = ["ce_api.hip", "ce_denoise.hip", "ce_inst_reg_h1_f0.hip", "ce_inst_reg_h1_f1.hip", "ce_inst_reg_h2_f0.hip",
+           "ce_inst_reg_h2_f1.hip", "ce_inst_gen_h1.hip", "ce_inst_gen_h2.hip"]
+HEADERS = ["ce_plan.h", "ce_estimate_kernel.h", "ce_inst.inc"]
 
 CE_ABI_VERSION = 2
 CE_MAX_CDM, CE_MAX_HOPS, CE_MAX_SYMBOLS = 2, 2, 14
@@ -67,19 +71,20 @@ EXPORTS_DENOISE = ["ce_denoiser_create", "ce_denoiser_destroy", "ce_denoise_batc
 EXTRA_FLAGS = {"ce_denoise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: Path | None = None) -> Path:
     """hipcc --offload-arch=gfx950 -> csrc/libce_hip.so (cross-compiles without a GPU): one object per source
     (compiled concurrently, each with its own flags), then one link."""
     from concurrent.futures import ThreadPoolExecutor
 
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / "ce_plan.h", INCLUDE / "ce_hip.h", INCLUDE / "ce_denoise.h", Path(__file__)]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+    deps = srcs + [CSRC / h for h in HEADERS] + [INCLUDE / "ce_hip.h", INCLUDE / "ce_denoise.h", Path(__file__)]
+    target = Path(out) if out is not None else LIB_PATH
+    if out is None and not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    objdir = CSRC / ".build"
+    objdir = CSRC / ".build" if out is None else Path(str(target) + ".obj")   # diagnostic builds (tools/) keep their own objects
     objdir.mkdir(exist_ok=True)
-    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags]
 
     def compile_one(src: Path) -> Path:
         obj = objdir / (src.stem + ".o")
@@ -89,13 +94,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
         objs = list(pool.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(o) for o in objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(target)] + [str(o) for o in objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return target
 
 
 _lib = None

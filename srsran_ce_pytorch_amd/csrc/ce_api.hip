@@ -12,7 +12,6 @@
 #include <string>
 #include <vector>
 
-#include <algorithm>
 #include "ce_plan.h"
 
 struct ce_plan {
@@ -139,6 +138,20 @@ bool mmse_matrix(const uint16_t* sc, int m, double scs, double tau, double nsr, 
 
 }  // namespace
 
+// Routes a launch / prepare to the translation unit holding the plan's instantiation (ce_inst_*.hip).
+static int kernel_op(int op, const CeDevPlan& P, const CeLaunchCtx& c) {
+  const int key = CE_KERNEL_KEY(P.feat, P.n_layers, P.reg_nd, P.reg_kpt);
+  const bool two = P.n_hops == 2;
+  if (P.reg_nd == 0 || P.feat == 3) return two ? ce_tu_gen_h2(op, key, c) : ce_tu_gen_h1(op, key, c);
+  if (P.feat == 0) return two ? ce_tu_reg_h2_f0(op, key, c) : ce_tu_reg_h1_f0(op, key, c);
+  return two ? ce_tu_reg_h2_f1(op, key, c) : ce_tu_reg_h1_f1(op, key, c);
+}
+
+#if defined(CE_STAMPS)
+static unsigned long long* g_stamps = nullptr;  // diagnostic builds only (tools/stamps.py)
+extern "C" int ce_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; return 0; }
+#endif
+
 extern "C" {
 
 const char* ce_last_error(void) { return g_err.c_str(); }
@@ -155,7 +168,6 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (d->n_sym < 1 || d->n_sym > CE_MAX_SYMBOLS) return fail(CE_ERR_UNSUPPORTED, "n_sym=%d outside 1..%d", d->n_sym, CE_MAX_SYMBOLS);
   if (d->smoothing < CE_SMOOTH_NONE || d->smoothing > CE_SMOOTH_MMSE) return fail(CE_ERR_INVALID, "Unknown smoothing strategy %d.", d->smoothing);
   if (d->interp != CE_INTERP_LINEAR && d->interp != CE_INTERP_CNN) return fail(CE_ERR_INVALID, "unknown interp %d", d->interp);
-  if (d->interp == CE_INTERP_CNN && d->n_sym != CE_MAX_SYMBOLS) return fail(CE_ERR_UNSUPPORTED, "the in-painting path is built for 14-symbol grids");
   if (!(d->scs_hz > 0) || !(d->beta_dmrs > 0)) return fail(CE_ERR_INVALID, "scs and beta_dmrs must be positive");
 
   ce_plan* p = new (std::nothrow) ce_plan();
@@ -303,7 +315,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   P.n_pilots = n_pilots;
   P.noise_den = (double)n_cdm * n_pilots - 1.0;
   P.inv_n_pilots = 1.0 / n_pilots; P.inv_layers = 1.0 / (double)L; P.inv_noise_den = 1.0 / P.noise_den;
-  P.inv_denom_cdm = 1.0 / (double)n_cdm; P.inv_scs = 1.0 / d->scs_hz;
+  P.inv_denom_cdm = 1.0 / (double)n_cdm;
 
   if (d->smoothing == CE_SMOOTH_FILTER) {
     const int dpp0 = P.hop[0].dpp[0];
@@ -429,12 +441,9 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   }
   // Two hops whose fill rectangles share OFDM symbols (the reference harness describes both hops of a hopping
   // allocation with the slot's whole symbol range, scripts/validation/validate_case4.py:85-103): which hop an
-  // element belongs to then depends on its subcarrier as well, which only the element-wise writer resolves
+  // element belongs to then depends on its subcarrier as well, which only the element-wise writer resolves (for
+  // either interpolator: src/ce_dl_cnn.py:233-352 overwrites the same way)
   P.sym_overlap = (d->n_hops == 2 && std::max(P.hop[0].sym0, P.hop[1].sym0) < std::min(P.hop[0].sym1, P.hop[1].sym1)) ? 1 : 0;
-  if (P.sym_overlap && d->interp == CE_INTERP_CNN) {
-    delete p;
-    return fail(CE_ERR_UNSUPPORTED, "the in-painting writer needs hops with disjoint symbol ranges");
-  }
   // register path: one layer (two layers' pilots would spill: measured slower than re-reading), every hop
   // with the same DM-RS symbol count, band fits CE_KPT pilot REs per thread
   P.reg_kpt = getenv("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : n_re <= 2 * CE_THREADS ? 2 : n_re <= 4 * CE_THREADS ? 4 : CE_KPT);  // env: tuning knob
@@ -448,8 +457,14 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     if (same) P.reg_nd = nd;
   }
   if (getenv("CE_FORCE_GENERIC")) P.reg_nd = 0;  // tuning knob: always take the re-read path
+  // feature set the kernel must carry (ce_estimate_kernel.h): the register-path kernels are built without the
+  // extensions (one exception: the wide 2-symbol shape), plans that need them take the re-read path
+  P.feat = d->smoothing == CE_SMOOTH_FILTER ? 1 : 0;
+  if (d->smoothing == CE_SMOOTH_MMSE || (d->interp == CE_INTERP_CNN && !P.cnn_comb2)) P.feat = 3;
+  if (P.feat == 3 && P.reg_nd > 0 && !ce_reg_has_ext(P.n_hops, P.reg_nd, P.reg_kpt)) P.reg_nd = 0;
 
-  const CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
+  CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
+  if (const char* pad = getenv("CE_LDS_PAD_BYTES")) lay.total += atoi(pad) & ~15;  // tuning knob: lowers the workgroups resident per CU
   if (lay.total > 160 * 1024) { delete p; return fail(CE_ERR_UNSUPPORTED, "plan needs %d B of LDS (> 160 KiB)", lay.total); }
 
   ce_plan_info& I = p->info;
@@ -487,7 +502,18 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (e == hipSuccess) e = hipMemcpy(p->dev_re_idx, re_idx.data(), re_idx.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->dev_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
   int blocks_per_cu = 1, n_cu = 1;
-  if (e == hipSuccess) e = (hipError_t)ce_prepare_kernel(L, P.n_hops, P.reg_nd, P.reg_kpt, lay.total, &blocks_per_cu);
+  if (e == hipSuccess) {
+    CeLaunchCtx c = {};
+    c.lds = lay.total;
+    c.blocks_per_cu = &blocks_per_cu;
+    const int kr = kernel_op(CE_OP_PREPARE, P, c);
+    if (kr < 0) {
+      fail(CE_ERR_UNSUPPORTED, "no kernel for (layers %d, hops %d, reg_nd %d, kpt %d, feat %d)", L, P.n_hops, P.reg_nd, P.reg_kpt, P.feat);
+      ce_plan_destroy(p);
+      return CE_ERR_UNSUPPORTED;
+    }
+    e = (hipError_t)kr;
+  }
   if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device);
   p->grid_cap = blocks_per_cu * n_cu;
   if (e != hipSuccess) {
@@ -559,6 +585,10 @@ static int check_batch(const ce_plan* plan, const void* rx, const int64_t* rs, c
   a->out = (float2*)ch_est; a->noise = noise; a->rsrp = rsrp; a->epre = epre; a->ta = ta; a->cfo = cfo;
   a->n_items = n_slots * n_ports; a->n_ports = n_ports;
   a->item0 = 0; a->n_local = a->n_items;
+  a->stamps = nullptr;
+#if defined(CE_STAMPS)
+  a->stamps = g_stamps;
+#endif
   return CE_OK;
 }
 
@@ -571,7 +601,10 @@ int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_stri
   if (a.n_items == 0) return CE_OK;
   CeDeviceScope scope(plan->device);  // `stream` belongs to the plan's device
   if (scope.err != hipSuccess) return fail(CE_ERR_HIP, "device %d: %s", plan->device, hipGetErrorString(scope.err));
-  int e = ce_launch(plan->host, plan->dev_plan, plan->dev_re_idx, plan->dev_ta_inv, plan->dev_tw, a, plan->info.lds_bytes, plan->grid_cap, (hipStream_t)stream);
+  CeLaunchCtx c = {};
+  c.dplan = plan->dev_plan; c.re_idx = plan->dev_re_idx; c.ta_inv = plan->dev_ta_inv; c.tw = plan->dev_tw;
+  c.args = &a; c.lds = plan->info.lds_bytes; c.stream = (hipStream_t)stream;
+  int e = kernel_op(CE_OP_LAUNCH, plan->host, c);
   if (e != 0) return fail(CE_ERR_HIP, "kernel launch failed: %s", e > 0 ? hipGetErrorString((hipError_t)e) : "no kernel for this (layers, hops)");
   return CE_OK;
 }

@@ -8,14 +8,22 @@
 //   ls              S2,S3,S5 T:584-613  EPRE, LS (x conj(pilot)), de-rotation, DM-RS average -> P in LDS
 //   despread        S6  T:620-628
 //   smooth_*        S7  T:633-668   mean | virtual pilots (T:69-140) + RC FIR (T:459-493)
-//   time_alignment  S8  T:670-698   pruned 4096-point inverse DFT (3 radix-16 passes, only the residues
-//                                   mod 16 that carry pilots, only the 288 examined bins), arg-max
 //   residual        S9,S11 T:700-730 reconstructed pilots, noise, RSRP
+//   [time_alignment S8  T:670-698   pruned 4096-point inverse DFT (3 radix-16 passes, only the residues
+//                                   mod 16 that carry pilots, only the 288 examined bins), arg-max -- see below]
 // then once per item:
 //   write_grid      S10 + epilogue T:237-354, T:921-929  linear interpolation, symbol replicate, CFO ramp
+// and, while the grid's stores drain, per hop:
+//   time_alignment  S8  (above) -- nothing the grid needs depends on it, so it runs after the writer
+//
+// This header holds the kernel template; the translation units ce_inst_*.hip instantiate slices of the
+// (layers, hops, register-path shape, feature set) space so they compile in parallel.
+#pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+
+#include <atomic>
 
 #include "ce_plan.h"
 
@@ -31,6 +39,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_MIN_WAVES
 #define CE_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for (3 workgroups per CU; 4 would spill)
 #endif
+#ifndef CE_MIN_WAVES_LIGHT
+#define CE_MIN_WAVES_LIGHT 3   // the same for single-hop register-path kernels built without the FIR ("none" / "mean" smoothing)
+#endif
 #ifndef CE_MW4_LIMIT
 #define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
 #endif
@@ -40,42 +51,63 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_NH2_MW2_FROM
 #define CE_NH2_MW2_FROM 15  // two hops: from this many pilot REs x symbols per thread on, 2 workgroups per CU with everything in registers
 #endif
+// Feature set compiled into an instantiation (template parameter FEAT): a register-path kernel only carries the
+// smoothing code its plans run, so e.g. the headline kernel's register allocation is not shaped by the MFMA block
+// of the mmse extension or the iterated in-painting it never executes.
+//   CE_FEAT_FIR  the raised-cosine FIR with virtual pilots (Smoothing="filter", T:637-664) and the CNNSmoothingAlpha blend
+//   CE_FEAT_EXT  the unpinned mmse extension (MFMA) and ce_dl_cnn's iterated in-painting (masks without a closed form)
+// "none" / "mean" smoothing, both interpolation closed forms and every writer are in all kernels.
+constexpr int CE_FEAT_FIR = 1, CE_FEAT_EXT = 2;
+
 // Register budget of the register-path kernels by pilot REs x DM-RS symbols per thread (KPT * ND): workgroups per CU
 // the allocator must leave room for, and whether the DM-RS symbols stay in registers next to the received pilots
 // (otherwise the three stages that use them re-read them through L2).  The 3-symbol wide kernel measured 2.93 ms at
 // 2 workgroups per CU with everything in registers vs 3.23 ms at 3 with the symbols re-read (3.6 ms generic path).
-constexpr int ce_min_waves(int nh, int nd, int kpt) {
+constexpr int ce_min_waves(int nh, int nd, int kpt, int feat) {
   const int n = nd * kpt;
   if (nd == 0) return CE_MIN_WAVES;
-  if (nh == 1) return n <= CE_MW4_LIMIT ? 4 : n <= 14 ? CE_MIN_WAVES : 2;
+  if (nh == 1) return n <= CE_MW4_LIMIT ? 4 : n <= 14 ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
   return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
 }
 constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
   const int n = nd * kpt;
   return nd > 0 && (nh == 1 || n <= 8 || n >= CE_NH2_MW2_FROM);
 }
+// Where the time-alignment stage runs: after the grid writer (the read -> estimate -> write chain of an item is shorter by
+// its longest stage, which then overlaps the draining stores), or inside the hop loop before it.  Same arithmetic either way.
+#ifndef CE_TA_LATE
+#define CE_TA_LATE -1   // -1: per-shape policy below; 0 / 1: force (A/B builds)
+#endif
+// Policy from a same-box A/B of both placements over tools/perf_cases.py (profiles/round2_ta_placement_ab.txt): late wins
+// 4-8 % where two hops run the estimation twice per item (one layer) and 1-2 % for 2-4 layers of one hop; early wins
+// 8 % for the 3-symbol wide kernel (2 workgroups per CU: the late stage keeps a slot from its next item), 3-4 % for
+// 2 layers x 2 hops and for 2 hops x 2 symbols in the KPT = 4 tier; everything else is within 1 %.
+constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
+  if (CE_TA_LATE >= 0) return CE_TA_LATE != 0;
+  if (layers == 1) return nh == 2 && !(nd == 2 && kpt == 4);
+  return nh == 1;
+}
 #ifndef CE_RELOAD_RESID
 #define CE_RELOAD_RESID 0 // 1: the residual stage re-reads rx / pilots instead of keeping them in registers across smoothing
-#endif
-#ifndef CE_PERSIST
-#define CE_PERSIST 0      // 1: persistent workgroups that prefetch the next item's pilots before writing
 #endif
 
 #if defined(CE_STAMPS)
 // diagnostic build only (tools/stamps.py): per-stage wall-clock stamps of thread 0, written to a buffer
-// nothing else reads; never compiled into the shipped library
-__device__ unsigned long long* g_ce_stamps;
+// nothing else reads (CeKernelArgs::stamps, set through ce_debug_set_stamps); never compiled into the shipped library
 #define STAMP(i)                                                      \
   do {                                                                \
-    if (threadIdx.x == 0 && g_ce_stamps) g_ce_stamps[item * 16 + (i)] = wall_clock64(); \
+    if (threadIdx.x == 0 && a.stamps) a.stamps[item * 16 + (i)] = wall_clock64(); \
   } while (0)
-#define STAMP_W3(i)                                                   \
+// where the workgroup runs: HW_ID (wave / SIMD / CU / SH / SE fields) in the low word, XCC_ID in the high word
+#define STAMP_HWID(i)                                                 \
   do {                                                                \
-    if (threadIdx.x == NT - 64 && g_ce_stamps) g_ce_stamps[item * 16 + (i)] = wall_clock64(); \
+    if (threadIdx.x == 0 && a.stamps)                                 \
+      a.stamps[item * 16 + (i)] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | \
+                                  (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                      \
   } while (0)
 #else
 #define STAMP(i)
-#define STAMP_W3(i)
+#define STAMP_HWID(i)
 #endif
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -385,7 +417,12 @@ __device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils
       const int e = q >> 4;
       virtual_pilots(Pl, n_re, n_pils, e != 0, q & 15, vmx, vin, vid, [&](int dist, float2 val) { vpb[e * 16 + dist] = val; });
     }
-    if (q < 2 * PAD) {  // same wave as the lanes that just wrote vpb: DS operations of a wave execute in order
+    // the lanes below read vpb entries other lanes of this wave just wrote: make the writes visible to the wave
+    // (and keep the compiler from moving the reads above them); no workgroup barrier is involved
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (q < 2 * PAD) {
       em = q < PAD ? q : n_re - 2 * PAD + q;
 #pragma unroll
       for (int j = 0; j < NTAP; ++j) {
@@ -524,13 +561,15 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
 // KPT = pilot REs per thread on the register path: CE_KPT for wide bands, 1 / 2 for bands of <= NT / 2 NT pilots
 // (<= 42 / 85 PRB at comb 2), whose kernels then need 40-50 fewer VGPRs and run four workgroups per CU -- narrow
 // allocations are latency-bound, so residency is what they are short of.
-template <int L, int NH, int ND, int KPT>
-__global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
+// FEAT = the smoothing / in-painting code compiled in (CE_FEAT_*).
+template <int L, int NH, int ND, int KPT, int FEAT>
+__global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
                                                          const uint16_t* __restrict__ re_idx,
                                                          const uint16_t* __restrict__ ta_inv,
                                                          const float2* __restrict__ tw, CeKernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool REG = ND > 0;
+  constexpr bool TA_LATE = ce_ta_late(L, NH, ND, KPT, FEAT);
   constexpr int NC = (L + 1) / 2;
   const int tid0 = threadIdx.x;
   int tid = tid0;
@@ -570,9 +609,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
     tab[i] = make_float2(plan->hop[h].alpha[c][r], __int_as_float(plan->hop[h].r_ord[c][r]));
   }
 
-  // Register path: received pilot REs and DM-RS symbols of (item, hop), KPT per thread.  Hop 0 of the
-  // NEXT item is requested before the current item's grid is written, so the HBM latency of the only
-  // dependent global read hides behind ~367 KB of stores.
+  // Register path: received pilot REs and DM-RS symbols of (item, hop), KPT per thread.
   float2 xr[REG ? KPT * ND : 1];
   // PREG: the DM-RS symbols stay in registers next to the received pilots; otherwise (3 symbols x CE_KPT REs, or two
   // hops with more than 8 per thread) the three stages that use them re-read them -- the Rx ports of a slot share
@@ -623,26 +660,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
       }
     }
   };
-  if (blockIdx.x < a.n_local) load_hop(a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local), 0);
-
-#if CE_PERSIST
-  // persistent workgroups: items blockIdx.x, blockIdx.x + gridDim.x, ...
-#pragma unroll 1
-  for (int64_t wg = blockIdx.x; wg < a.n_local; wg += gridDim.x) {
-  const int64_t item = a.item0 + item_of(wg, a.n_ports, a.n_local);
-#else
-  {
-  if (blockIdx.x >= a.n_local) return;
+  if (blockIdx.x >= a.n_local) return;  // the grid is exactly n_local workgroups
   const int64_t item = a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local);
-#endif
-  // Everything a stage derives from the thread index and the plan is loop-invariant; left alone, the
-  // compiler hoists all of it out of the item loop and keeps ~100 extra registers live across every
-  // stage.  An opaque copy of the thread index (and a memory barrier for the plan reads) keeps each
-  // stage's temporaries local to the stage.
-#if CE_PERSIST
-  tid = tid0;
-  asm volatile("" : "+v"(tid) : : "memory");
-#endif
+  load_hop(item, 0);
   const int64_t slot = item / a.n_ports;
   const int port = (int)(item - slot * a.n_ports);
   const float2* rx = a.rx + slot * a.rs_b + port * a.rs_r;
@@ -657,8 +677,115 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
       return pil_sl[(unsigned)k * (unsigned)a.ps_re];
     }
   };
-  double tot_epre = 0.0, tot_noise = 0.0, tot_rsrp = 0.0, tot_ta = 0.0;
+  // ------------------------------------------------------------ time alignment of one hop (S8)
+  double tot_ta = 0.0;
+  auto time_alignment = [&](int h) {
+    const CeDevHop& lh = lp->hop[h];
+    const float2* Ph = P + h * L * n_re_pad;
+    // x[n] = P[k] at the pilot subcarriers of the LAST CDM group (for every layer, T:672-675), else 0;
+    // X[k] = sum_n x[n] W^(nk), W = exp(+j 2 pi / 4096), wanted only for k in [0,144) U [3952,4096).
+    // n = r + 16 n':  X[k] = sum_r W^(rk) Y_r[k mod 256],  Y_r = 256-point IDFT of x[r + 16 n'] done as
+    // two radix-16 passes in LDS; residues r without pilots (half of them for a comb-2 DM-RS) are skipped.
+    if (!(CE_ABLATE & 1)) {
+      float pw0 = 0.f, pw1 = 0.f;  // bins tid and tid + NT of the 288 examined (b < 144: delay side, else advance side)
+      const int b0 = tid, b1 = tid + NT;
+      constexpr int NB = 2 * CE_TA_HALF;
+      const int nres = lh.ta_nres;
+      const uint16_t* inv = ta_inv + lh.ta_inv_off;
+      const int ri = tid >> 4, a4 = tid & 15;
+      const unsigned long long res_packed = lh.ta_res_packed;
+      auto bin_power = [&](int k) -> float {
+        const int q = k & 255, off = (q & 15) * 17 + (q >> 4);
+        float2 acc = make_float2(0.f, 0.f);
+        for (int i = 0; i < nres; ++i) {
+          const int m = ((int)((res_packed >> (4 * i)) & 15u) * k) & (CE_FFT_SIZE - 1);  // W4096^(r k)
+          acc = cadd(acc, cmul(cmul(tw256[m >> 4], tw16[m & 15]), scratch[i * CE_TA_ROW + off]));
+        }
+        return acc.x * acc.x + acc.y * acc.y;
+      };
+      // subcarrier n -> ordinal of the pilot it carries (last CDM group), or -1
+      const int contig = lh.contig, dpp_last = lh.dpp[NC - 1], prb0 = lh.prb_start, nprb = lh.n_prbs;
+      const unsigned long long ord_packed = lh.ord_packed;
+      auto pilot_at = [&](int n) -> int {
+        if (contig) {
+          const int q = n / 12, rem = n - 12 * q, pq = q - prb0;
+          const int o = (int)((ord_packed >> (4 * rem)) & 15u);
+          return (pq >= 0 && pq < nprb && o != 15) ? pq * dpp_last + o : -1;
+        }
+        const unsigned idx = inv[n];
+        return idx == 0xFFFFu ? -1 : (int)idx;
+      };
+#pragma unroll 1
+      for (int l = 0; l < L; ++l) {
+        const float2* Pl = Ph + l * n_re_pad;
+        if (ri < nres) {  // pass 1: DFT16 over b of x[r + 16 a + 256 b], times W256^(a c)
+          const int r = (int)((res_packed >> (4 * ri)) & 15u);
+          float2 v[16];
+#pragma unroll
+          for (int b = 0; b < 16; ++b) {
+            const int idx = pilot_at(r + 16 * a4 + 256 * b);
+            v[b] = idx >= 0 ? Pl[idx] : make_float2(0.f, 0.f);
+          }
+          idft16(v);
+          float2* dst = scratch + ri * CE_TA_ROW + a4;
+          dst[0] = v[0];
+#pragma unroll
+          for (int c = 1; c < 16; ++c) dst[c * 17] = cmul(v[c], tw256[a4 * c]);
+        }
+        __syncthreads();
+        if (ri < nres) {  // pass 2 (in place): DFT16 over a for fixed c = a4 -> Y_r[c + 16 d] at [c*17 + d]
+          float2* rowp = scratch + ri * CE_TA_ROW + a4 * 17;
+          float2 v[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = rowp[i];
+          idft16(v);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) rowp[i] = v[i];
+        }
+        __syncthreads();
+        if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0);
+        if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1);
+        __syncthreads();
+      }
+      // arg-max with first-index tie break on each side: key = (power bits, ~index)
+      unsigned long long kh = 0ull, kt = 0ull;
+      auto offer = [&](int b, float pw) {
+        if (b < NB) {
+          const int idx = b < CE_TA_HALF ? b : b - CE_TA_HALF;
+          const unsigned long long key = ((unsigned long long)__float_as_uint(pw) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
+          if (b < CE_TA_HALF) kh = key > kh ? key : kh;
+          else kt = key > kt ? key : kt;
+        }
+      };
+      offer(b0, pw0);
+      offer(b1, pw1);
+      kh = wave_max_u64(kh);
+      kt = wave_max_u64(kt);
+      unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 48);  // own slot: no barrier needed after use
+      if ((tid & 63) == 0) {
+        ared[(tid >> 6) * 2] = kh;
+        ared[(tid >> 6) * 2 + 1] = kt;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long mh = 0ull, mt = 0ull;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          mh = ared[2 * w] > mh ? ared[2 * w] : mh;
+          mt = ared[2 * w + 1] > mt ? ared[2 * w + 1] : mt;
+        }
+        const float vd = __uint_as_float((unsigned)(mh >> 32)), va = __uint_as_float((unsigned)(mt >> 32));
+        const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
+        const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
+        const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
+        tot_ta += (double)i_max / (double)CE_FFT_SIZE / lp->scs;  // T:698, the reference's two float64 divisions
+      }
+    }
+  };
+
+  double tot_epre = 0.0, tot_noise = 0.0, tot_rsrp = 0.0;
   STAMP(0);
+  STAMP_HWID(12);
 
 #pragma unroll 1
   for (int h = 0; h < NH; ++h) {
@@ -669,7 +796,10 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
     const float n_dmrs_f = (float)n_dmrs;
     const bool has_cfo = REG ? (ND >= 2) : (hp.has_cfo != 0);
     if (h > 0) load_hop(item, h);
-    if (NH > 1) {  // same reason as at the top of the item loop: keep each stage's thread-derived temporaries local
+    if (NH > 1) {
+      // Everything a stage derives from the thread index and the plan is loop-invariant; left alone, the compiler
+      // hoists all of it out of the hop loop and keeps it live across every stage.  An opaque copy of the thread index
+      // (and a memory barrier for the plan reads) keeps each stage's temporaries local to the stage.
       tid = tid0;
       asm volatile("" : "+v"(tid) : : "memory");
     }
@@ -831,7 +961,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
           Ph[l * n_re_pad + k] = make_float2((float)(m[2 * l] / (double)n_re), (float)(m[2 * l + 1] / (double)n_re));
       }
       __syncthreads();
-    } else if (lp->smoothing == CE_SMOOTH_MMSE) {
+    } else if ((FEAT & CE_FEAT_EXT) && lp->smoothing == CE_SMOOTH_MMSE) {
       // EXTENSION (not in the reference): block LMMSE smoothing.  Y = W X for every block of 32 pilots of the layer
       // at once: X^T (blocks as columns) and W^T are staged in the scratch, the complex product is four real
       // v_mfma_f32_16x16x4_f32 chains per 16x16 output tile (A = W: lane -> [m = lane&15][k = lane>>4],
@@ -889,7 +1019,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
         }
         __syncthreads();
       }
-    } else if (lp->smoothing == CE_SMOOTH_FILTER) {
+    } else if ((FEAT & CE_FEAT_FIR) && lp->smoothing == CE_SMOOTH_FILTER) {
       const int n_pils = lp->n_pils, rc_len = lp->rc_len;
       const int pad = rc_len / 2;
       const double vmx = lp->vp_mx, vin = lp->vp_inv_n, vid = lp->vp_inv_denom;
@@ -1015,110 +1145,10 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
       tot_noise += v[1];
       tot_rsrp += lp->beta * lp->beta * v[2] * (double)n_dmrs;
     }
-
-    STAMP(6);
-    // ------------------------------------------------------------ time alignment (S8)
-    // x[n] = P[k] at the pilot subcarriers of the LAST CDM group (for every layer, T:672-675), else 0;
-    // X[k] = sum_n x[n] W^(nk), W = exp(+j 2 pi / 4096), wanted only for k in [0,144) U [3952,4096).
-    // n = r + 16 n':  X[k] = sum_r W^(rk) Y_r[k mod 256],  Y_r = 256-point IDFT of x[r + 16 n'] done as
-    // two radix-16 passes in LDS; residues r without pilots (half of them for a comb-2 DM-RS) are skipped.
-    if (!(CE_ABLATE & 1)) {
-      float pw0 = 0.f, pw1 = 0.f;  // bins tid and tid + NT of the 288 examined (b < 144: delay side, else advance side)
-      const int b0 = tid, b1 = tid + NT;
-      constexpr int NB = 2 * CE_TA_HALF;
-      const int nres = lh.ta_nres;
-      const uint16_t* inv = ta_inv + lh.ta_inv_off;
-      const int ri = tid >> 4, a4 = tid & 15;
-      const unsigned long long res_packed = lh.ta_res_packed;
-      auto bin_power = [&](int k) -> float {
-        const int q = k & 255, off = (q & 15) * 17 + (q >> 4);
-        float2 acc = make_float2(0.f, 0.f);
-        for (int i = 0; i < nres; ++i) {
-          const int m = ((int)((res_packed >> (4 * i)) & 15u) * k) & (CE_FFT_SIZE - 1);  // W4096^(r k)
-          acc = cadd(acc, cmul(cmul(tw256[m >> 4], tw16[m & 15]), scratch[i * CE_TA_ROW + off]));
-        }
-        return acc.x * acc.x + acc.y * acc.y;
-      };
-      // subcarrier n -> ordinal of the pilot it carries (last CDM group), or -1
-      const int contig = lh.contig, dpp_last = lh.dpp[NC - 1], prb0 = lh.prb_start, nprb = lh.n_prbs;
-      const unsigned long long ord_packed = lh.ord_packed;
-      auto pilot_at = [&](int n) -> int {
-        if (contig) {
-          const int q = n / 12, rem = n - 12 * q, pq = q - prb0;
-          const int o = (int)((ord_packed >> (4 * rem)) & 15u);
-          return (pq >= 0 && pq < nprb && o != 15) ? pq * dpp_last + o : -1;
-        }
-        const unsigned idx = inv[n];
-        return idx == 0xFFFFu ? -1 : (int)idx;
-      };
-#pragma unroll 1
-      for (int l = 0; l < L; ++l) {
-        const float2* Pl = Ph + l * n_re_pad;
-        if (ri < nres) {  // pass 1: DFT16 over b of x[r + 16 a + 256 b], times W256^(a c)
-          const int r = (int)((res_packed >> (4 * ri)) & 15u);
-          float2 v[16];
-#pragma unroll
-          for (int b = 0; b < 16; ++b) {
-            const int idx = pilot_at(r + 16 * a4 + 256 * b);
-            v[b] = idx >= 0 ? Pl[idx] : make_float2(0.f, 0.f);
-          }
-          idft16(v);
-          float2* dst = scratch + ri * CE_TA_ROW + a4;
-          dst[0] = v[0];
-#pragma unroll
-          for (int c = 1; c < 16; ++c) dst[c * 17] = cmul(v[c], tw256[a4 * c]);
-        }
-        __syncthreads();
-        if (ri < nres) {  // pass 2 (in place): DFT16 over a for fixed c = a4 -> Y_r[c + 16 d] at [c*17 + d]
-          float2* rowp = scratch + ri * CE_TA_ROW + a4 * 17;
-          float2 v[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = rowp[i];
-          idft16(v);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) rowp[i] = v[i];
-        }
-        __syncthreads();
-        if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0);
-        if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1);
-        __syncthreads();
-      }
-      // arg-max with first-index tie break on each side: key = (power bits, ~index)
-      unsigned long long kh = 0ull, kt = 0ull;
-      auto offer = [&](int b, float pw) {
-        if (b < NB) {
-          const int idx = b < CE_TA_HALF ? b : b - CE_TA_HALF;
-          const unsigned long long key = ((unsigned long long)__float_as_uint(pw) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
-          if (b < CE_TA_HALF) kh = key > kh ? key : kh;
-          else kt = key > kt ? key : kt;
-        }
-      };
-      offer(b0, pw0);
-      offer(b1, pw1);
-      kh = wave_max_u64(kh);
-      kt = wave_max_u64(kt);
-      unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 48);  // own slot: no barrier needed after use
-      if ((tid & 63) == 0) {
-        ared[(tid >> 6) * 2] = kh;
-        ared[(tid >> 6) * 2 + 1] = kt;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        unsigned long long mh = 0ull, mt = 0ull;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          mh = ared[2 * w] > mh ? ared[2 * w] : mh;
-          mt = ared[2 * w + 1] > mt ? ared[2 * w + 1] : mt;
-        }
-        const float vd = __uint_as_float((unsigned)(mh >> 32)), va = __uint_as_float((unsigned)(mt >> 32));
-        const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
-        const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
-        const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
-        tot_ta += (double)i_max * (1.0 / (double)CE_FFT_SIZE) * lp->inv_scs;  // T:698
-      }
-    }
+    if constexpr (!TA_LATE) time_alignment(h);
   }
 
+  STAMP(6);
   STAMP(7);
   // ---------------------------------------------------------------- slot-level epilogue (T:898-937)
   const bool apply_rot = cfo_comp && lp->cfo_estimated && !(CE_ABLATE & 16);
@@ -1143,33 +1173,12 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
       a.rsrp[item] = tot_rsrp * np * lp->inv_layers;
       a.epre[item] = tot_epre * np;
       a.noise[item] = tot_noise * lp->inv_noise_den;
-      a.ta[item] = (NH == 2) ? tot_ta * 0.5 : tot_ta;
       a.cfo[item] = lp->cfo_estimated ? cfo * lp->scs : __longlong_as_double(0x7FF8000000000000ll);
     }
   }
   __syncthreads();
 
   STAMP(8);
-#if CE_PERSIST
-  {
-    // Prefetch the next item's pilots; they are consumed at the top of the next trip.  The index is tied
-    // (empty asm) to an LDS value that only exists after the epilogue's barrier, so the scheduler cannot hoist
-    // these 28 loads above the TA stage, where their 56 destination registers would not fit.
-    int64_t nxt = wg + gridDim.x;
-    const float dep = rot_final[0].x;
-    asm volatile("" : "+s"(nxt) : "v"(dep));
-    if (nxt < a.n_local) {
-      load_hop(a.item0 + item_of(nxt, a.n_ports, a.n_local), 0);
-    } else {
-      // last trip: give the registers a fresh (dead) value, otherwise the old pilots count as live across
-      // the TA stage just to reach the loop's back edge
-#pragma unroll
-      for (int i = 0; i < (REG ? KPT * ND : 1); ++i) xr[i] = make_float2(0.f, 0.f);
-#pragma unroll
-      for (int i = 0; i < (PREG ? KPT * ND * L : 1); ++i) pr[i] = make_float2(0.f, 0.f);
-    }
-  }
-#endif
   // ---------------------------------------------------------------- interpolate + replicate + CFO ramp (S10)
   const int n_sym = lp->n_sym;
   const int row = n_sym * L;  // complex values per subcarrier
@@ -1232,6 +1241,32 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
     return acc;
   };
 
+  // ce_dl_cnn.py's in-painting iterated as the reference does (masks without a closed form): the response of every
+  // (hop, layer) over the whole grid band -> scratch rows of cnn_h_stride elements (zeros outside the hop band)
+  const bool cnn_iterated = (FEAT & CE_FEAT_EXT) && lp->interp == CE_INTERP_CNN && !lp->cnn_comb2;
+  auto inpaint_rows = [&]() {
+    if constexpr ((FEAT & CE_FEAT_EXT) != 0) {
+      const int hs = lp->cnn_h_stride, n_sc = lp->n_sc;
+      float2* pong = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(scratch) + lp->cnn_pong_off);
+      unsigned char* m_a = reinterpret_cast<unsigned char*>(scratch) + lp->cnn_m_off;
+      unsigned char* m_b = m_a + ((lp->cnn_n_max + 15) & ~15);
+#pragma unroll 1
+      for (int hl = 0; hl < NH * L; ++hl) {
+        const int h = hl / L, l = hl - h * L;
+        const CeDevHop& lh = lp->hop[h];
+        float2* row = scratch + hl * hs;
+        for (int i = tid; i < n_sc; i += NT)
+          if (i < lh.sc0 || i >= lh.sc0 + lh.n_sc_hop) row[i] = make_float2(0.f, 0.f);
+        const int c = l >> 1;
+        const unsigned mask12 = (unsigned)((lh.mask12 >> (16 * c)) & 0xFFFu);
+        const int n_it = lh.n_sc_hop / 8 > 6 ? lh.n_sc_hop / 8 : 6;  // C:293
+        cnn_inpaint_layer(row + lh.sc0, pong, m_a, m_b, P + (h * L + l) * n_re_pad, lh.n_sc_hop, mask12, lh.dpp[c], n_it,
+                          lp->cnn_rcp, tid);
+      }
+      __syncthreads();
+    }
+  };
+
   if (CE_ABLATE & 8) {
   } else if (n_sym == CE_MAX_SYMBOLS && !lp->sym_overlap) {
     // Fast writer (hop of an element decided by its symbol alone).  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
@@ -1258,26 +1293,10 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
       rsel[e] = h < 0 ? make_float2(0.f, 0.f) : rot_final[sym];  // rot_final == 1 when no CFO ramp applies
     }
     float4* out4 = reinterpret_cast<float4*>(out);
-    if (lp->interp == CE_INTERP_CNN && !lp->cnn_comb2) {
+    if (cnn_iterated) {
       // in-painted response for every (hop, layer), whole band at once, then the same phase-owning store loop
       const int hs = lp->cnn_h_stride, n_sc = lp->n_sc;
-      float2* pong = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(scratch) + lp->cnn_pong_off);
-      unsigned char* m_a = reinterpret_cast<unsigned char*>(scratch) + lp->cnn_m_off;
-      unsigned char* m_b = m_a + ((lp->cnn_n_max + 15) & ~15);
-#pragma unroll 1
-      for (int hl = 0; hl < NH * L; ++hl) {
-        const int h = hl / L, l = hl - h * L;
-        const CeDevHop& lh = lp->hop[h];
-        float2* row = scratch + hl * hs;
-        for (int i = tid; i < n_sc; i += NT)
-          if (i < lh.sc0 || i >= lh.sc0 + lh.n_sc_hop) row[i] = make_float2(0.f, 0.f);
-        const int c = l >> 1;
-        const unsigned mask12 = (unsigned)((lh.mask12 >> (16 * c)) & 0xFFFu);
-        const int n_it = lh.n_sc_hop / 8 > 6 ? lh.n_sc_hop / 8 : 6;  // C:293
-        cnn_inpaint_layer(row + lh.sc0, pong, m_a, m_b, P + (h * L + l) * n_re_pad, lh.n_sc_hop, mask12, lh.dpp[c], n_it,
-                          lp->cnn_rcp, tid);
-      }
-      __syncthreads();
+      inpaint_rows();
       const float2* HA = scratch + (hsel[0] * L + lsel[0]) * hs;
       const float2* HB = scratch + (hsel[1] * L + lsel[1]) * hs;
       if (tid < ACTIVE) {
@@ -1324,7 +1343,10 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
       }
     }
   } else {
-    // generic writer (any n_sym, hops that share symbols): decode (subcarrier, symbol, layer) per element
+    // generic writer (any n_sym, hops that share symbols -- the harness's own two-hop convention,
+    // scripts/validation/validate_case4.py:85-103 -- for either interpolator): decode (subcarrier, symbol, layer) per
+    // element; where the hops' rectangles overlap the later hop wins (T:872-896, src/ce_dl_cnn.py:233-352)
+    if (cnn_iterated) inpaint_rows();
     auto elem = [&](int sc, int rem) -> float2 {
       const int sym = rem / L, l = rem - sym * L;
       float2 val = make_float2(0.f, 0.f);
@@ -1333,7 +1355,10 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
         const CeDevHop& lh = lp->hop[h];
         const int p = sc - lh.sc0;
         if (sym >= lh.sym0 && sym < lh.sym1 && p >= 0 && p < lh.n_sc_hop) {
-          val = interp_at(h, l, p);
+          if (lp->interp != CE_INTERP_CNN) val = interp_at(h, l, p);
+          else if (lp->cnn_comb2 == 1) val = cnn2_at(h, l, p);
+          else if (lp->cnn_comb2 == 2) val = cnnfp_at(h, l, p);
+          else if constexpr ((FEAT & CE_FEAT_EXT) != 0) val = scratch[(h * L + l) * lp->cnn_h_stride + sc];
           if (apply_rot) val = cmul(val, rot_final[sym]);
           break;
         }
@@ -1363,69 +1388,58 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT)) void ce_estimate_ker
     }
   }
   STAMP(10);
-  __syncthreads();  // the next item reuses P, the scratch and the phasor tables
-  }  // item loop
+  if constexpr (TA_LATE) {
+    // ---------------------------------------------------------------- time alignment of each hop (S8)
+    // Nothing the grid needs depends on it, so it runs here, while this workgroup's stores drain: the read ->
+    // estimate -> write chain of an item is shorter by this stage, the longest of the estimation.
+    __syncthreads();  // the writers are done with the scratch
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) {
+      if (NH > 1) {
+        tid = tid0;
+        asm volatile("" : "+v"(tid) : : "memory");
+      }
+      time_alignment(h);
+    }
+  }
+  if (tid == 0) a.ta[item] = (NH == 2) ? tot_ta / 2.0 : tot_ta;  // T:918-919
+  STAMP(11);
 }
 
-#if defined(CE_STAMPS)
-}  // namespace
-extern "C" int ce_debug_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ce_stamps), &p, sizeof(p)); }
-namespace {
-#endif
-
-template <int L, int NH, int ND, int KPT>
-int launch_t(const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv, const float2* tw,
-             const CeKernelArgs& args, int lds, int grid_cap, hipStream_t stream) {
-  const unsigned grid = (unsigned)((!CE_PERSIST || args.n_local < grid_cap) ? args.n_local : grid_cap);
-  hipLaunchKernelGGL((ce_estimate_kernel<L, NH, ND, KPT>), dim3(grid), dim3(NT), lds, stream, dplan, re_idx, ta_inv, tw,
-                     args);
+template <int L, int NH, int ND, int KPT, int FEAT>
+int launch_t(const CeLaunchCtx& c) {
+  hipLaunchKernelGGL((ce_estimate_kernel<L, NH, ND, KPT, FEAT>), dim3((unsigned)c.args->n_local), dim3(NT), c.lds, c.stream,
+                     c.dplan, c.re_idx, c.ta_inv, c.tw, *c.args);
   return (int)hipGetLastError();
 }
 
-// sets the dynamic-LDS limit and reports how many workgroups fit a CU (the persistent grid is CUs x that)
-template <int L, int NH, int ND, int KPT>
-int prepare_t(int lds, int* blocks_per_cu) {
-  const void* fn = reinterpret_cast<const void*>(&ce_estimate_kernel<L, NH, ND, KPT>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+// Raises the kernel's dynamic-LDS limit to what this plan needs and reports how many workgroups fit a CU.  Plans of
+// different sizes share an instantiation, so the limit only ever grows (per device): a small plan created after a
+// large one must not lower it under the large plan's launches.
+template <int L, int NH, int ND, int KPT, int FEAT>
+int prepare_t(const CeLaunchCtx& c) {
+  const void* fn = reinterpret_cast<const void*>(&ce_estimate_kernel<L, NH, ND, KPT, FEAT>);
+  static std::atomic<int> lds_limit[CE_MAX_DEVICES];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= CE_MAX_DEVICES) return (int)hipErrorInvalidDevice;
+  int cur = lds_limit[dev].load();
+  while (c.lds > cur) {
+    // concurrent creators may both set the attribute; the larger value wins in lds_limit and is (re)applied by its owner
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
+    if (e != hipSuccess) return (int)e;
+    if (lds_limit[dev].compare_exchange_weak(cur, c.lds)) break;
+  }
   int nb = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NT, lds);
-  *blocks_per_cu = nb > 0 ? nb : 1;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NT, c.lds);
+  *c.blocks_per_cu = nb > 0 ? nb : 1;
   return (int)e;
 }
 
+template <int L, int NH, int ND, int KPT, int FEAT>
+int run_t(int op, const CeLaunchCtx& c) {
+  return op == CE_OP_LAUNCH ? launch_t<L, NH, ND, KPT, FEAT>(c) : prepare_t<L, NH, ND, KPT, FEAT>(c);
+}
+
 }  // namespace
-
-// (layers, hops, register-path DM-RS count, pilot REs per thread).  The register path (ND > 0) only exists for one
-// layer; the wide kernel (KPT = CE_KPT, bands up to 298 PRB) holds 1-2 DM-RS symbols of pilots in registers, the
-// narrow-band ones (KPT 1 / 2 / 4: bands up to 42 / 85 / 170 PRB of a comb-2 DM-RS) up to 4 -- as far as they fit
-// the 168 VGPRs of 3 workgroups per CU without spilling (ce_api.hip: reg_nd).
-#define CE_CASE(FN, L, NH, ND, KC, KT, ...) \
-  case L * 1000 + NH * 100 + ND * 10 + KC: return FN<L, NH, ND, KT>(__VA_ARGS__);
-#define CE_NARROW(FN, NH, ND, ...) \
-  CE_CASE(FN, 1, NH, ND, 1, 1, __VA_ARGS__) CE_CASE(FN, 1, NH, ND, 2, 2, __VA_ARGS__)
-#define CE_HOPS(FN, NH, ...)                                                                              \
-  CE_CASE(FN, 1, NH, 0, 0, CE_KPT, __VA_ARGS__) CE_CASE(FN, 1, NH, 1, 0, CE_KPT, __VA_ARGS__)           \
-  CE_CASE(FN, 1, NH, 2, 0, CE_KPT, __VA_ARGS__) CE_NARROW(FN, NH, 1, __VA_ARGS__)                       \
-  CE_NARROW(FN, NH, 2, __VA_ARGS__) CE_NARROW(FN, NH, 3, __VA_ARGS__) CE_NARROW(FN, NH, 4, __VA_ARGS__) \
-  CE_CASE(FN, 1, NH, 1, 4, 4, __VA_ARGS__) CE_CASE(FN, 1, NH, 2, 4, 4, __VA_ARGS__)                     \
-  CE_CASE(FN, 1, NH, 3, 4, 4, __VA_ARGS__) CE_CASE(FN, 1, NH, 4, 4, 4, __VA_ARGS__)                     \
-  CE_CASE(FN, 1, NH, 3, 0, CE_KPT, __VA_ARGS__)                                                          \
-  CE_CASE(FN, 2, NH, 0, 0, CE_KPT, __VA_ARGS__) CE_CASE(FN, 3, NH, 0, 0, CE_KPT, __VA_ARGS__)           \
-  CE_CASE(FN, 4, NH, 0, 0, CE_KPT, __VA_ARGS__)
-#define CE_DISPATCH(FN, ...)                                                                                     \
-  switch (n_layers * 1000 + n_hops * 100 + reg_nd * 10 + (reg_nd && reg_kpt < CE_KPT ? reg_kpt : 0)) {          \
-    CE_HOPS(FN, 1, __VA_ARGS__)                                                                                  \
-    CE_HOPS(FN, 2, __VA_ARGS__)                                                                                  \
-    default: return -1;                                                                                          \
-  }
-
-int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,
-              const float2* tw, const CeKernelArgs& args, int lds_bytes, int grid_cap, hipStream_t stream) {
-  const int n_layers = hplan.n_layers, n_hops = hplan.n_hops, reg_nd = hplan.reg_nd, reg_kpt = hplan.reg_kpt;
-  CE_DISPATCH(launch_t, dplan, re_idx, ta_inv, tw, args, lds_bytes, grid_cap, stream)
-}
-
-int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int reg_kpt, int lds_bytes, int* blocks_per_cu) {
-  CE_DISPATCH(prepare_t, lds_bytes, blocks_per_cu)
-}

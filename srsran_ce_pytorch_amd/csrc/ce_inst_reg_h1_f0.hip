@@ -1,0 +1,5 @@
+// Instantiation unit: register-path kernels, 1 hop(s), feature set 0 (ce_inst.inc).
+#define CE_TU_NAME ce_tu_reg_h1_f0
+#define CE_TU_NH 1
+#define CE_TU_FEAT 0
+#include "ce_inst.inc"

@@ -47,11 +47,12 @@ struct CeDevPlan {
   int32_t n_sc, n_sym, n_layers, n_cdm, n_hops, smoothing, cfo_comp, interp;
   int32_t n_re, n_re_pad, n_pils, rc_len, ext_len, filt_lpp;
   int32_t cfo_estimated, reg_nd;      // reg_nd: DM-RS symbols per hop held in registers (0 = re-read path)
+  int32_t feat, pad0;                 // CE_FEAT_* bits the plan's kernel must carry (ce_estimate_kernel.h)
   int32_t reg_kpt, sym_overlap;              // pilot REs per thread on the register path: smallest of 1, 2, 4, CE_KPT covering n_re; sym_overlap: the hops' fill rectangles share symbols
   int32_t scratch_bytes, wr_ch_log2;  // LDS scratch size; log2 of the writer's subcarrier chunk
   float beta_f;
   double beta, scs, denom_cdm, n_pilots, noise_den;
-  double inv_n_pilots, inv_layers, inv_noise_den, inv_denom_cdm, inv_scs;  // reciprocals: one multiply instead of a float64 divide
+  double inv_n_pilots, inv_layers, inv_noise_den, inv_denom_cdm;  // reciprocals: one multiply instead of a float64 divide
   double sst[CE_MAX_SYMBOLS];         // symbolStartTime (T:809-820)
   double sst_dmrs[CE_MAX_HOPS][CE_MAX_SYMBOLS];  // symbolStartTime at each hop's DM-RS symbols
   double rc[CE_MAX_RC_TAPS];          // RC taps, unit sum (T:184-234)
@@ -80,6 +81,7 @@ struct CeKernelArgs {
   int64_t n_items;
   int32_t n_ports;
   int64_t item0, n_local;  // a launch covers work items [item0, item0 + n_local) of the n_items batch
+  unsigned long long* stamps;  // diagnostic builds (-DCE_STAMPS) only: 16 wall-clock stamps per item; otherwise null
 };
 
 // LDS carve-up shared by host (sizing) and device (offsets); all offsets multiples of 16 B.
@@ -125,7 +127,27 @@ struct CeDeviceScope {
 // sets the calling thread's ce_last_error() text and returns `code` (ce_api.hip)
 int ce_fail(int code, const char* fmt, ...);
 
-int ce_launch(const CeDevPlan& hplan, const CeDevPlan* dplan, const uint16_t* re_idx, const uint16_t* ta_inv,
-              const float2* tw, const CeKernelArgs& args, int lds_bytes, int grid_cap, hipStream_t stream);
-int ce_prepare_kernel(int n_layers, int n_hops, int reg_nd, int reg_kpt, int lds_bytes, int* blocks_per_cu);
-
+// One call into the translation unit that holds the instantiation a plan selected (ce_inst_*.hip).
+enum { CE_OP_LAUNCH = 0, CE_OP_PREPARE = 1 };
+#define CE_MAX_DEVICES 64
+struct CeLaunchCtx {
+  const CeDevPlan* dplan;
+  const uint16_t* re_idx;
+  const uint16_t* ta_inv;
+  const float2* tw;
+  const CeKernelArgs* args;  // CE_OP_LAUNCH
+  int lds;
+  hipStream_t stream;
+  int* blocks_per_cu;        // CE_OP_PREPARE (the plan's device is current)
+};
+// key = feat * 10000 + layers * 1000 + reg_nd * 10 + (narrow KPT, or 0 for the wide / generic kernels); -1: not built
+#define CE_KERNEL_KEY(feat, layers, reg_nd, reg_kpt) \
+  ((feat) * 10000 + (layers) * 1000 + (reg_nd) * 10 + ((reg_nd) && (reg_kpt) < CE_KPT ? (reg_kpt) : 0))
+int ce_tu_reg_h1_f0(int op, int key, const CeLaunchCtx& c);   // register path (one layer), one hop, none / mean smoothing
+int ce_tu_reg_h1_f1(int op, int key, const CeLaunchCtx& c);   //                               ... + RC filter
+int ce_tu_reg_h2_f0(int op, int key, const CeLaunchCtx& c);   // two hops
+int ce_tu_reg_h2_f1(int op, int key, const CeLaunchCtx& c);
+int ce_tu_gen_h1(int op, int key, const CeLaunchCtx& c);      // re-read path (1-4 layers), every feature set; + the wide headline kernel with extensions
+int ce_tu_gen_h2(int op, int key, const CeLaunchCtx& c);
+// whether the register path (reg_nd > 0) has an instantiation carrying CE_FEAT_EXT for this shape
+static inline bool ce_reg_has_ext(int n_hops, int reg_nd, int reg_kpt) { return n_hops == 1 && reg_nd == 2 && reg_kpt == CE_KPT; }

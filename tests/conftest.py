@@ -61,7 +61,7 @@ def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what
     """Comparison protocol used everywhere: channel estimate error relative to the largest
     reference magnitude; scalars relative, except the residual noise whose floor is rounding
     noise of the EPRE (it is a difference of nearly equal quantities when nothing is smoothed);
-    TA must match exactly to float64 rounding (it is a multiple of 1/(4096*scs));
+    TA must be bit-identical (an integer bin index through the reference's two float64 divisions, T:698);
     cfo NaN <=> "not estimated"."""
     scale = float(np.abs(ref_ch).max())
     err = float(np.abs(got_ch - ref_ch).max()) / scale
@@ -71,7 +71,7 @@ def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what
     assert abs(rsrp - r_rsrp) <= tol_sc * abs(r_rsrp), f"{what}: rsrp {rsrp} vs {r_rsrp}"
     assert abs(epre - r_epre) <= tol_sc * abs(r_epre), f"{what}: epre {epre} vs {r_epre}"
     assert abs(noise - r_noise) <= tol_sc * max(abs(r_noise), 1e-2 * abs(r_epre)), f"{what}: noise {noise} vs {r_noise}"
-    assert abs(ta - r_ta) <= 1e-12 * max(abs(r_ta), 1e-9), f"{what}: time alignment {ta} vs {r_ta}"
+    assert ta == r_ta, f"{what}: time alignment {ta!r} vs {r_ta!r}"      # index work: bit-exact (T:698)
     if np.isnan(r_cfo):
         assert np.isnan(cfo), f"{what}: cfo should be 'not estimated'"
     else:

@@ -124,3 +124,26 @@ def test_maximum_grid_width_and_unsupported_sizes():
     h1, h2, cfg = S.numpy_hops(S.case_spec("too_wide", 400, [S.hop_spec([2, 11], 0, 400)]))
     with pytest.raises(NotImplementedError):            # 4800 subcarriers: the reference would truncate its IFFT input
         E.make_plan(h1, h2, cfg, 1.0, 1, 400, 14, dev)
+
+
+def test_large_plan_survives_a_later_small_plan_of_the_same_kernel():
+    """Plans of different LDS sizes share a kernel instantiation; the dynamic-LDS limit of the instantiation must
+    only ever grow, or relaunching the cached large plan after a small one was created would fail (or clip)."""
+    dev = torch.device("cuda:0")
+    BOTH = [S.TYPE1_CDM0, S.TYPE1_CDM1]
+    big = S.case_spec("l4_big", 273, [S.hop_spec([2, 11], 0, 273, re_masks=BOTH)], n_layers=4, seed=3)
+    small = S.case_spec("l4_small", 52, [S.hop_spec([2, 11], 5, 6, re_masks=BOTH)], n_layers=4, seed=4)
+    outs = []
+    for case in (big, small, big):
+        b = S.build_case(case, 1)
+        h1, h2, cfg = S.numpy_hops(case)
+        plan = E.make_plan(h1, h2, cfg, case["beta"], 4, case["n_prb_grid"], 14, dev)
+        rg = torch.as_tensor(b.grids, device=dev)[None]
+        out = E.estimate_with_plan(plan, rg, torch.as_tensor(b.pilots, device=dev))
+        torch.cuda.synchronize()
+        outs.append((plan.lds_bytes, out[0].clone(), b))
+    assert outs[0][0] > outs[1][0]
+    assert torch.equal(outs[0][1], outs[2][1])
+    b = outs[0][2]
+    ref = O.srs_channel_estimator(b.grids[0], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+    assert np.abs(outs[2][1][0, 0].cpu().numpy() - ref[0]).max() <= 2e-5 * np.abs(ref[0]).max()

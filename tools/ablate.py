@@ -35,14 +35,10 @@ def main():
     ap.add_argument("--smoothing", default="filter")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
-    csrc = ROOT / "srsran_ce_pytorch_amd" / "csrc"
+    from srsran_ce_pytorch_amd import _lib
     for v in a.variants:
         name, _, flags = v.partition("=")
-        flags, _, ksrc = flags.partition("@")          # name=flags@kernel_source (default: the tree's ce_kernels.hip)
-        kfile = str(ROOT / ksrc) if ksrc else str(csrc / "ce_kernels.hip")
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT/'include'}", f"-I{csrc}",
-               "-o", "/tmp/libce_hip_ablate.so", str(csrc / "ce_api.hip"), str(csrc / "ce_denoise.hip"), kfile] + flags.split()
-        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        _lib.build(force=True, extra_flags=flags.split(), out="/tmp/libce_hip_ablate.so")   # all translation units, concurrently
         r = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), a.slots, a.ports, a.smoothing, a.layers)], capture_output=True, text=True,
                            env=dict(os.environ, CE_HIP_LIB="/tmp/libce_hip_ablate.so"))   # never touches the shipped library  # stderr (compiler warnings) dropped
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -79,6 +79,13 @@ def golden_cases():
         (dict(CS("cnn_layers4_comb2", 52, [H([2, 7, 11], 20, 7, re_masks=BOTH)], n_layers=4, seed=26), cnn_alpha=0.25), "C", 1),
         # a wide type-2 hop: 409 iterations reach the fixed point, the HIP writer takes the closed form (binomial over linear fill)
         (dict(CS("cnn_type2_273", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])], n_layers=2, seed=28), cnn_alpha=0.2), "C", 1),
+        # ce_dl_cnn through the element-wise writer: the harness's two-hop convention (validate_case4.py:85-103: both hops carry
+        # the slot's whole symbol range; hop 2 overwrites, C:233-352), partly overlapping rectangles with a mask that is
+        # iterated exactly, and 12-symbol grids (no CFO ramp possible: one DM-RS symbol / compensation off)
+        (CS("cnn_case4like_fullslot_hops", 52, [H([0, 4], 3, 3, 0, 14), H([8, 12], 28, 3, 0, 14)], scs=15e3, seed=40), "C", 2),
+        (dict(CS("cnn_type2_overlap_hops", 52, [H([1, 4], 5, 8, 0, 10, [S.TYPE2_CDM0]), H([8, 12], 9, 8, 6, 8, [S.TYPE2_CDM0])], n_layers=2, seed=41), cnn_alpha=0.3), "C", 1),
+        (CS("cnn_12sym_1dmrs", 52, [H([3], 5, 6, 0, 12)], n_sym=12, seed=42), "C", 2),
+        (CS("cnn_12sym_type2_nocfo", 52, [H([2, 9], 20, 4, 1, 10, [S.TYPE2_CDM0])], n_sym=12, cfo_compensate=False, smoothing="mean", seed=43), "C", 1),
         (CS("cnn_comb2_odd_2hop", 52, [H([3], 0, 5, 0, 7, [S.TYPE1_CDM1]), H([10], 47, 5, 7, 7, [S.TYPE1_CDM1])], smoothing="mean", seed=27), "C", 1),
     ]
     return cases

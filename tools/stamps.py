@@ -1,38 +1,63 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): build with -DCE_STAMPS and print where a workgroup's time goes.
+
+    python tools/stamps.py [case-substring ...] [-DFLAG ...]      (cases: tools/perf_matrix.py's table)
+
 Stamps are wall_clock64() (100 MHz) of thread 0 at stage boundaries; shares, not run times."""
-import ctypes as C, subprocess, sys
+import ctypes as C, os, sys
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-csrc = ROOT / "srsran_ce_pytorch_amd" / "csrc"
-flags = sys.argv[1:] 
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT/'include'}", f"-I{csrc}", "-DCE_STAMPS=1",
-                "-o", "/tmp/libce_hip_stamps.so", str(csrc / "ce_api.hip"), str(csrc / "ce_denoise.hip"), str(csrc / "ce_kernels.hip")] + flags, check=True)
-import os
+sys.path.insert(0, str(ROOT / "tools"))
+flags = [a for a in sys.argv[1:] if a.startswith("-")]
+only = [a for a in sys.argv[1:] if not a.startswith("-")] or ["L1 2dmrs filter"]
+from srsran_ce_pytorch_amd import _lib as _L
+_L.build(force=True, extra_flags=["-DCE_STAMPS=1"] + flags, out="/tmp/libce_hip_stamps.so")
 os.environ["CE_HIP_LIB"] = "/tmp/libce_hip_stamps.so"      # never overwrite the shipped library with a diagnostic build
+import importlib
 import torch
 from srsran_ce_pytorch_amd import estimator as E, synth as S, _lib
+importlib.reload(_lib)
 lib = _lib.load()
 lib.ce_debug_set_stamps.argtypes = [C.c_void_p]
-names = ["init", "load", "cfo", "rot", "ls", "smooth", "resid", "ta", "epilog", "Hbuild", "write"]
+from perf_cases import CASES
+names = ["load", "cfo", "rot", "ls", "smooth", "resid", "-", "epilog", "Hbuild", "write", "ta"]
 dev = torch.device("cuda:0")
-for slots, ports in [(64, 4), (8192, 4)]:
-    case = S.bench_case("filter", 1, seed=1)
-    h1, h2, cfg = S.numpy_hops(case)
-    plan = E.make_plan(h1, h2, cfg, case["beta"], 1, 273, 14, dev)
-    rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
-    n = slots * ports
-    st = torch.zeros((n, 16), dtype=torch.int64, device=dev)
-    lib.ce_debug_set_stamps(st.data_ptr())
-    out = E.estimate_with_plan(plan, rx, pil)
-    torch.cuda.synchronize()
-    E.estimate_with_plan(plan, rx, pil, out)
-    torch.cuda.synchronize()
-    t = st.cpu().numpy().astype(np.float64) * 0.01   # us
-    d = np.diff(t[:, :11], axis=1)
-    print(f"--- {n} items: median us per stage (total {np.median(t[:,10]-t[:,0]):.1f} us; kernel span {(t[:,10].max()-t[:,0].min()):.0f} us)")
-    print("  ".join(f"{nm}={np.median(d[:, i]):.2f}" for i, nm in enumerate(names[1:])))
-    if t[:, 11].max() > 0:
-        print(f"  smoothing detail: conv-phase1 done (wave 0) +{np.median(t[:,11]-t[:,4]):.2f}  virtual pilots done (wave 3) +{np.median(t[:,12]-t[:,4]):.2f}  after barrier +{np.median(t[:,13]-t[:,4]):.2f}  stage end +{np.median(t[:,5]-t[:,4]):.2f}")
+for name, case, interp in CASES:
+    if not any(o in name for o in only):
+        continue
+    for slots, ports in [(64, 4), (8192, 4)]:
+        h1, h2, cfg = S.numpy_hops(case)
+        plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], 14, dev, interp)
+        rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
+        n = slots * ports
+        st = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+        lib.ce_debug_set_stamps(st.data_ptr())
+        out = E.estimate_with_plan(plan, rx, pil)
+        torch.cuda.synchronize()
+        E.estimate_with_plan(plan, rx, pil, out)
+        torch.cuda.synchronize()
+        t = st.cpu().numpy().astype(np.float64) * 0.01   # us
+        t[:, 9] = np.where(t[:, 9] > 0, t[:, 9], t[:, 8])  # the direct writer has no staging stamp
+        d = np.diff(t[:, :12], axis=1)
+        print(f"--- {name}: {n} items: median us per stage (item total {np.median(t[:,11]-t[:,0]):.1f} us, to end of writer {np.median(t[:,10]-t[:,0]):.1f}; kernel span {(t[:,11].max()-t[:,0].min()):.0f} us)")
+        print("  ".join(f"{nm}={np.median(d[:, i]):.2f}" for i, nm in enumerate(names)), flush=True)
+        # residency: which CU each workgroup ran on (HW_ID bits 8-15: CU / SH / SE, XCC_ID), how many were resident
+        # on a CU on average, and how long a CU waited between one workgroup's last stamp and the next one's first
+        hw = st.cpu().numpy()[:, 12]
+        cu = ((hw >> 32) & 0xF) * 256 + ((hw >> 8) & 0xFF)
+        span = t[:, 11].max() - t[:, 0].min()
+        res, gaps = [], []
+        for c in np.unique(cu):
+            m = cu == c
+            s0, e0 = np.sort(t[m, 0]), np.sort(t[m, 11])
+            res.append((t[m, 11] - t[m, 0]).sum() / span)
+            k = int(round(res[-1] + 0.5)) or 1
+            if len(s0) > 2 * k:
+                # with k slots busy, the i-th start follows the (i-k)-th end
+                gaps.extend((s0[k:] - e0[:-k]).tolist())
+        print(f"  {len(np.unique(cu))} CUs seen; resident workgroups per CU: mean {np.mean(res):.2f} (min {np.min(res):.2f}, max {np.max(res):.2f}); "
+              f"end-of-TA -> next start on the same CU: median {np.median(gaps) if gaps else float('nan'):.2f} us; "
+              f"mean item {np.mean(t[:,11]-t[:,0]):.1f} us, p95 {np.percentile(t[:,11]-t[:,0], 95):.1f} us", flush=True)
+        del rx, pil, out
