@@ -18,8 +18,9 @@ Workloads (BASELINE.json configs):
                         interpolation; the reference has no Conv2d / fp16 / learned weights).
 
 Prints ONE JSON line on rank 0 with the driver's fields plus ``roofline`` (HBM; algorithmic bytes
-per launch / HIP-event launch time) and, at N=1, ``cpu_baseline`` (the CPU oracle = a port of the
-reference's algorithm, timed on the host cores on a bounded sample of the same workload).
+per launch / HIP-event launch time) and, at N=1, ``cpu_baseline`` (CPU ports of the reference's algorithm --
+the loop-style ce_rule_baseline form and the tensorized form -- timed on the host cores on bounded samples of the same
+workload) and ``secondary`` (the other parity-pinned workloads, a few launches each).
 """
 from __future__ import annotations
 
@@ -53,10 +54,13 @@ DENOISE_FLOP_PER_PIXEL = 2 * 9 * (2 * 16 + 16 * 16 + 16 * 2)   # useful MACs x 2
 
 
 def _cpu_worker(args):
-    """Oracle (CPU port of the reference algorithm) on one slot's ports, repeated; returns items done."""
-    case, n_ports, reps, seed, interp, denoise = args
+    """One CPU restatement of the reference algorithm on one slot's ports, repeated; returns (items done, seconds).
+    flavour: "tensorized" = oracle/ce_oracle.py (ce_rule_tensorized.py), "baseline_loop" = oracle/ce_oracle_baseline.py
+    (the loop-style ce_rule_baseline.py BASELINE.json names), "cnn" = the ce_dl_cnn.py fill, "+denoise" = extension."""
+    case, n_ports, reps, seed, flavour, denoise = args
     sys.path.insert(0, str(ROOT / "oracle"))
     import ce_oracle as O
+    import ce_oracle_baseline as OB
     from srsran_ce_pytorch_amd import synth as S
 
     b = S.build_case(dict(case, seed=seed), n_ports)
@@ -66,7 +70,11 @@ def _cpu_worker(args):
         weights = random_weights(0)
 
     def one(r):
-        out = O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=interp)
+        if flavour == "baseline_loop":
+            out = OB.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+        else:
+            out = O.srs_channel_estimator(b.grids[r], b.pilots, b.beta, b.hop1, b.hop2, b.config,
+                                          interp="cnn" if flavour == "cnn" else "linear")
         if denoise:
             DO.denoise(out[0], weights)
 
@@ -80,26 +88,71 @@ def _cpu_worker(args):
     return reps * n_ports, time.perf_counter() - t0
 
 
-def cpu_baseline(case, n_ports, target_core_seconds=20.0, interp="linear", denoise=False):
-    """Bounded sample of the same workload on the host cores (fork happens BEFORE any GPU init)."""
+def _cpu_leg(case, n_ports, flavour, denoise, target_core_seconds, cores):
     import multiprocessing as mp
 
-    cores = min(16, len(os.sched_getaffinity(0)))
-    n1, t1 = _cpu_worker((case, n_ports, 3, 999, interp, denoise))         # per-item estimate on one core
+    n1, t1 = _cpu_worker((case, n_ports, 2, 999, flavour, denoise))     # per-item estimate on one core
     per_item = t1 / n1
     reps = max(1, int(target_core_seconds / cores / (per_item * n_ports)))
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(case, n_ports, reps, 1000 + i, interp, denoise) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(case, n_ports, reps, 1000 + i, flavour, denoise) for i in range(cores)])
     wall = time.perf_counter() - t0
-    items = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
-    slots = items / n_ports
-    return dict(value=slots / busy, unit="slots/s", cores=cores, kind="port",
-                sample=f"{int(slots)} slots x {n_ports} ports of the same 273-PRB workload through oracle/ce_oracle.py "
-                       f"(numpy port of {'ce_dl_cnn' if interp == 'cnn' else 'ce_rule_tensorized'}{' + oracle/ce_denoise_oracle.py' if denoise else ''}), {cores} worker processes, {busy:.1f} s busy / {wall:.1f} s wall; "
-                       f"{per_item * 1e3:.2f} ms per slot-port on one core")
+    slots = sum(r[0] for r in res) / n_ports
+    return dict(slots_per_s=slots / busy, slots=int(slots), busy_s=busy, wall_s=wall, ms_per_slot_port_one_core=per_item * 1e3)
+
+
+def cpu_baseline(case, n_ports, target_core_seconds=20.0, interp="linear", denoise=False):
+    """Bounded samples of the same workload on the host cores (forks happen BEFORE any GPU init): the loop-style
+    restatement of ce_rule_baseline.py -- the baseline north_star names, `value` -- and the tensorized restatement next
+    to it, plus BASELINE.json configs[0] (25 PRB / 1 DM-RS / 1 Rx / LS only, one slot at a time on one core)."""
+    from srsran_ce_pytorch_amd import synth as S
+
+    cores = min(16, len(os.sched_getaffinity(0)))
+    fast = _cpu_leg(case, n_ports, "cnn" if interp == "cnn" else "tensorized", denoise, target_core_seconds * 0.4, cores)
+    out = dict(unit="slots/s", cores=cores, kind="port")
+    if interp == "cnn" or denoise:                                      # these workloads have no loop-style reference form
+        name = "ce_dl_cnn" if interp == "cnn" else "ce_rule_tensorized"
+        out.update(value=fast["slots_per_s"], flavour=name + (" + Conv2d denoiser (extension)" if denoise else ""))
+        loop = None
+    else:
+        loop = _cpu_leg(case, n_ports, "baseline_loop", False, target_core_seconds * 0.6, cores)
+        out.update(value=loop["slots_per_s"], flavour="ce_rule_baseline (loop-style)", tensorized_value=fast["slots_per_s"],
+                   baseline_loop_ms_per_slot_port=loop["ms_per_slot_port_one_core"],
+                   tensorized_ms_per_slot_port=fast["ms_per_slot_port_one_core"])
+    c0 = S.config1_case()                                               # configs[0], the reference's own CPU-runnable case
+    n0, t0 = _cpu_worker((c0, 1, 20, 7, "baseline_loop", False))
+    out["config0_ms"] = t0 / n0 * 1e3
+    legs = [("oracle/ce_oracle_baseline.py (numpy port of ce_rule_baseline, per-gap / per-layer loops)", loop),
+            (f"oracle/ce_oracle.py (numpy port of {'ce_dl_cnn' if interp == 'cnn' else 'ce_rule_tensorized'}"
+             f"{' + oracle/ce_denoise_oracle.py' if denoise else ''})", fast)]
+    out["sample"] = "; ".join(f"{l['slots']} slots x {n_ports} ports of the same 273-PRB workload through {what}, {cores} worker "
+                              f"processes, {l['busy_s']:.1f} s busy / {l['wall_s']:.1f} s wall, {l['ms_per_slot_port_one_core']:.2f} ms per slot-port on one core"
+                              for what, l in legs if l is not None) + \
+        f"; config0_ms = configs[0] (25 PRB in a 52-PRB grid, 1 DM-RS symbol, 1 Rx, LS only) through the loop-style port, one core"
+    return out
+
+
+def time_steps(step, barrier, steps, warmup, make_events=None):
+    """The driver's timing contract for one rank: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by
+    `barrier()` (process-group barrier + device synchronise) on both sides.  Returns (wall seconds of the bracket,
+    average ms per step between two events recorded on the launch stream, or None without `make_events`)."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    ev = make_events() if make_events is not None else None
+    t0 = time.perf_counter()
+    if ev is not None:
+        ev[0].record()                                              # same stream the kernel is launched on
+    for _ in range(steps):
+        step()
+    if ev is not None:
+        ev[1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, (ev[0].elapsed_time(ev[1]) / steps if ev is not None else None)
 
 
 def secondary_lines(E, S, plan, case, rx, pilots, out, n_slots, n_ports, dev, iters=5):
@@ -207,18 +260,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                                                    # same stream the kernel is launched on
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    elapsed, kernel_ms = time_steps(step, barrier, args.steps, args.warmup,
+                                    lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
     elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms], "cpu" if rehearse else dev)  # measurement only, not data path
 
     # sanity: the batch really was estimated (finite outputs, CFO in the generated range)

@@ -140,6 +140,18 @@ int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_stri
                       const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est,
                       double* noise, double* rsrp, double* epre, double* ta, double* cfo_hz, void* stream);
 
+/* Diagnostic form of ce_estimate_batch for per-stage tests: same launch, same results, and in
+ * addition the intermediates of process_hop the fused kernel otherwise never materialises:
+ *  stage_estimates  out, complex64 [slot][port][2][n_hops][n_layers][n_re]: the pilot-RE channel estimate of each hop
+ *                   after S5/S6 (LS, DM-RS average, CDM de-spread; T:593-628) and after S7 (frequency smoothing, T:633-668)
+ *  stage_scalars    out, float64 [slot][port][n_hops][2]: the hop's CFO normalised to the SCS (T:426; not written when
+ *                   the hop has one DM-RS symbol) and the signed arg-max bin of its time alignment (T:686-696)
+ * n_re / n_hops as in ce_plan_info / the descriptor.  Not for the hot loop (extra ~16 B per pilot RE of stores). */
+int ce_estimate_batch_stages(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
+                             const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est,
+                             double* noise, double* rsrp, double* epre, double* ta, double* cfo_hz,
+                             void* stage_estimates, double* stage_scalars, void* stream);
+
 /* Times `iters` back-to-back launches of ce_estimate_batch with HIP events recorded on `stream`
  * (after `warmup` untimed ones); *avg_ms = mean kernel-launch duration.  Used by bench.py for the
  * roofline line.  Synchronous. */

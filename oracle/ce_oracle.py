@@ -295,8 +295,9 @@ def smooth_filter_column(col: np.ndarray, rc: np.ndarray, n_pils: int) -> np.nda
 
 def process_hop(hop: HopConfig, pilots: np.ndarray, smoothing: str, rg: np.ndarray, scs: float,
                 cp_ms: np.ndarray, cfo_compensate: bool, beta: float, sst: np.ndarray,
-                channel: np.ndarray, interp: str = "linear", cnn_alpha: float = 0.0, mmse_cfg=None):
-    """Returns (epre, cfo_hop|None, ta, noise, rsrp) contributions of this hop; fills ``channel``."""
+                channel: np.ndarray, interp: str = "linear", cnn_alpha: float = 0.0, mmse_cfg=None, stages=None):
+    """Returns (epre, cfo_hop|None, ta, noise, rsrp) contributions of this hop; fills ``channel``.
+    ``stages`` (a list, tests only) receives a dict of this hop's intermediate results."""
     pilots = _c64(pilots)
     n_re, n_dmrs, n_layers = pilots.shape
     n_cdm = int(math.ceil(n_layers / 2))
@@ -328,6 +329,7 @@ def process_hop(hop: HopConfig, pilots: np.ndarray, smoothing: str, rg: np.ndarr
             p[0:2 * m:2] = avg
             p[1:2 * m:2] = avg
 
+    p_ls = p.copy()
     if smoothing == "mean":                                           # S7  T:633-668
         p = (np.ones_like(p) * np.mean(p, axis=0, keepdims=True, dtype=p.dtype)).astype(p.dtype)
     elif smoothing == "filter":
@@ -359,6 +361,10 @@ def process_hop(hop: HopConfig, pilots: np.ndarray, smoothing: str, rg: np.ndarr
     i_delay, i_adv = int(np.argmax(head)), int(np.argmax(tail))
     i_max = i_delay if float(head[i_delay]) >= float(tail[i_adv]) else -(HALF_CP - (i_adv + 1) + 1)
     ta = float(i_max) / float(FFT_SIZE) / float(scs)
+    if stages is not None:
+        side, i = (head, i_delay) if i_max >= 0 else (tail, i_adv)
+        stages.append(dict(p_ls=p_ls, p_smooth=p.copy(), cfo_hop=cfo_hop, ta_bin=i_max,
+                           ta_pw=[float(side[i - 1]) if i > 0 else -1.0, float(side[i]), float(side[i + 1]) if i + 1 < HALF_CP else -1.0]))
 
     # S9-S11: reconstruct the received pilots, fill the grid, residual + RSRP (T:700-730)
     est_rx = np.zeros_like(rx_pilots)
@@ -378,8 +384,9 @@ def process_hop(hop: HopConfig, pilots: np.ndarray, smoothing: str, rg: np.ndarr
 
 
 def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1: HopConfig, hop2: HopConfig,
-                          config: EstimatorConfig, interp: str = "linear"):
-    """Oracle for T:745-937 (``interp="cnn"`` selects the ce_dl_cnn.py fill, C:233-352).
+                          config: EstimatorConfig, interp: str = "linear", stages=None):
+    """Oracle for T:745-937 (``interp="cnn"`` selects the ce_dl_cnn.py fill, C:233-352).  ``stages``: an empty list that
+    receives one dict per hop (LS estimate, smoothed estimate, hop CFO, TA bin and the power around it) -- tests only.
 
     Returns (channel_est_rg (n_sc,n_sym,L) complex64, noise, rsrp, epre, time_alignment,
     cfo_hz) with float64 scalars; cfo_hz is None where the reference returns an empty tensor.
@@ -398,7 +405,7 @@ def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1: HopConfig, hop2:
     channel = np.zeros((rg.shape[0], rg.shape[1], n_layers), rg.dtype)
     n1 = int(np.asarray(hop1.DMRSsymbols, bool).sum())
     epre, cfo, ta, noise, rsrp = process_hop(hop1, pilots[:, :n1, :], smoothing, rg, scs, cp_ms,
-                                             cfo_compensate, float(beta_dmrs), sst, channel, interp, cnn_alpha, mmse_cfg)
+                                             cfo_compensate, float(beta_dmrs), sst, channel, interp, cnn_alpha, mmse_cfg, stages)
     all_dmrs = np.asarray(hop1.DMRSsymbols, bool).copy()
     h2 = np.asarray(hop2.DMRSsymbols)
     has_hop2 = h2.size != 0 and int(h2.astype(np.int64).sum()) != 0
@@ -409,7 +416,7 @@ def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1: HopConfig, hop2:
         assert np.array_equal(np.asarray(hop1.DMRSREmask), np.asarray(hop2.DMRSREmask)), \
             "The DM-RS mask should be the same for the two hops."
         e2, c2, t2, n2, r2 = process_hop(hop2, pilots[:, n1:, :], smoothing, rg, scs, cp_ms,
-                                         cfo_compensate, float(beta_dmrs), sst, channel, interp, cnn_alpha, mmse_cfg)
+                                         cfo_compensate, float(beta_dmrs), sst, channel, interp, cnn_alpha, mmse_cfg, stages)
         epre, ta, noise, rsrp = epre + e2, ta + t2, noise + n2, rsrp + r2
         if c2 is not None:
             cfo = (cfo + c2) / 2 if cfo is not None else c2          # T:605-609

@@ -62,7 +62,7 @@ class PlanHostView(C.Structure):
 
 
 EXPORTS = ["ce_plan_create", "ce_plan_destroy", "ce_plan_get_info", "ce_plan_derive_host", "ce_estimate_batch",
-           "ce_time_batch", "ce_last_error", "ce_abi_version"]
+           "ce_estimate_batch_stages", "ce_time_batch", "ce_last_error", "ce_abi_version"]
 EXPORTS_DENOISE = ["ce_denoiser_create", "ce_denoiser_destroy", "ce_denoise_batch"]   # include/ce_denoise.h (extension)
 
 
@@ -127,6 +127,8 @@ def load() -> C.CDLL:
     batch = [vp, vp, i64p, vp, i64p, C.c_int64, C.c_int32, vp, dp, dp, dp, dp, dp, vp]
     lib.ce_estimate_batch.argtypes = batch
     lib.ce_estimate_batch.restype = C.c_int
+    lib.ce_estimate_batch_stages.argtypes = batch[:-1] + [vp, dp, vp]
+    lib.ce_estimate_batch_stages.restype = C.c_int
     lib.ce_time_batch.argtypes = batch + [C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     lib.ce_time_batch.restype = C.c_int
     lib.ce_last_error.argtypes = []

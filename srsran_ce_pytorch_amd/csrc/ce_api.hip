@@ -422,12 +422,17 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       P.cnn_comb2 = comb2 ? 1 : converges ? 2 : 0;
     }
     if (d->interp == CE_INTERP_CNN && !P.cnn_comb2) {
-      // whole-band H rows for every (hop, layer) + a second x buffer + two mask byte arrays
+      // band-relative H rows for every (hop, layer) + a second x buffer + two mask byte arrays; when all rows together
+      // would not fit the LDS (many layers of wide hops) the writer in-paints and stores one row at a time
       int n_max = 0;
       for (int h = 0; h < d->n_hops; ++h) n_max = P.hop[h].n_sc_hop > n_max ? P.hop[h].n_sc_hop : n_max;
       P.cnn_n_max = n_max;
-      P.cnn_h_stride = (n_sc + 1) & ~1;
-      const int h_bytes = P.n_hops * L * P.cnn_h_stride * 8;
+      P.cnn_h_stride = (n_max + 1) & ~1;
+      const int aux = ((n_max + 1) & ~1) * 8 + 2 * ((n_max + 15) & ~15);
+      int rows = P.n_hops * L;
+      const int fixed = ce_lds_layout(P.n_hops, L, (n_re + 1) & ~1, 0).total;
+      if (fixed + rows * P.cnn_h_stride * 8 + aux > 160 * 1024 - 256) { rows = 1; P.cnn_rowwise = 1; }
+      const int h_bytes = rows * P.cnn_h_stride * 8;
       P.cnn_pong_off = h_bytes;
       P.cnn_m_off = h_bytes + ((n_max + 1) & ~1) * 8;
       const int cnn_need = P.cnn_m_off + 2 * ((n_max + 15) & ~15);
@@ -585,6 +590,7 @@ static int check_batch(const ce_plan* plan, const void* rx, const int64_t* rs, c
   a->out = (float2*)ch_est; a->noise = noise; a->rsrp = rsrp; a->epre = epre; a->ta = ta; a->cfo = cfo;
   a->n_items = n_slots * n_ports; a->n_ports = n_ports;
   a->item0 = 0; a->n_local = a->n_items;
+  a->stage_p = nullptr; a->stage_s = nullptr;
   a->stamps = nullptr;
 #if defined(CE_STAMPS)
   a->stamps = g_stamps;
@@ -592,12 +598,13 @@ static int check_batch(const ce_plan* plan, const void* rx, const int64_t* rs, c
   return CE_OK;
 }
 
-int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
-                      const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est, double* noise,
-                      double* rsrp, double* epre, double* ta, double* cfo_hz, void* stream) {
+static int launch_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
+                        const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est, double* noise,
+                        double* rsrp, double* epre, double* ta, double* cfo_hz, void* stage_p, double* stage_s, void* stream) {
   CeKernelArgs a;
   int rc = check_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, &a);
   if (rc != CE_OK) return rc;
+  a.stage_p = (float2*)stage_p; a.stage_s = stage_s;
   if (a.n_items == 0) return CE_OK;
   CeDeviceScope scope(plan->device);  // `stream` belongs to the plan's device
   if (scope.err != hipSuccess) return fail(CE_ERR_HIP, "device %d: %s", plan->device, hipGetErrorString(scope.err));
@@ -607,6 +614,20 @@ int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_stri
   int e = kernel_op(CE_OP_LAUNCH, plan->host, c);
   if (e != 0) return fail(CE_ERR_HIP, "kernel launch failed: %s", e > 0 ? hipGetErrorString((hipError_t)e) : "no kernel for this (layers, hops)");
   return CE_OK;
+}
+
+int ce_estimate_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
+                      const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est, double* noise,
+                      double* rsrp, double* epre, double* ta, double* cfo_hz, void* stream) {
+  return launch_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, nullptr, nullptr, stream);
+}
+
+int ce_estimate_batch_stages(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,
+                             const int64_t pil_strides[4], int64_t n_slots, int32_t n_ports, void* ch_est, double* noise,
+                             double* rsrp, double* epre, double* ta, double* cfo_hz, void* stage_estimates,
+                             double* stage_scalars, void* stream) {
+  if (!stage_estimates || !stage_scalars) return fail(CE_ERR_INVALID, "null stage buffers");
+  return launch_batch(plan, rx, rx_strides, pilots, pil_strides, n_slots, n_ports, ch_est, noise, rsrp, epre, ta, cfo_hz, stage_estimates, stage_scalars, stream);
 }
 
 int ce_time_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[4], const void* pilots,

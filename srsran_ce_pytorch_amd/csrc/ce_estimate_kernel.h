@@ -344,7 +344,7 @@ __device__ __forceinline__ float2 lp3x2(const float2* x, int i, int n) {
 // identity -- the comb-2 DM-RS reaches it after two iterations instead of max(6, n/8).  num/(den+eps) is
 // evaluated as num * (1/(den+eps)) with the five possible reciprocals tabulated (<= 1 ulp in float64
 // before the float32 round trip).  Result ends in `dst`.
-__device__ void cnn_inpaint_layer(float2* dst, float2* pong, unsigned char* m_a, unsigned char* m_b, const float2* Pl,
+__device__ __forceinline__ void cnn_inpaint_layer(float2* dst, float2* pong, unsigned char* m_a, unsigned char* m_b, const float2* Pl,
                                   int n, unsigned mask12, int dpp, int n_iters, const double* rcp, int tid) {
   for (int i = tid; i < n; i += NT) {
     const int q = i / 12, r = i - 12 * q;
@@ -677,6 +677,20 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
       return pil_sl[(unsigned)k * (unsigned)a.ps_re];
     }
   };
+  // Diagnostics (ce_estimate_batch_stages; a.stage_p is null in every ordinary launch): the pilot-RE channel estimate of
+  // hop h after stage `st` (0: LS + DM-RS average + de-spread, S5/S6; 1: after frequency smoothing, S7) as
+  // [item][stage][hop][layer][n_re]; a.stage_s [item][hop][2] = the hop's CFO (normalised to the SCS) and its TA bin.
+  auto dump_stage = [&](int st, int h) __attribute__((always_inline)) {
+    if (a.stage_p) {
+      float2* sp = a.stage_p + ((item * 2 + st) * NH + h) * (int64_t)(L * n_re);
+      const float2* Ph = P + h * L * n_re_pad;
+      for (int i = tid; i < L * n_re; i += NT) {
+        const int l = i / n_re;
+        sp[i] = Ph[l * n_re_pad + (i - l * n_re)];
+      }
+    }
+  };
+
   // ------------------------------------------------------------ time alignment of one hop (S8)
   double tot_ta = 0.0;
   auto time_alignment = [&](int h) {
@@ -779,6 +793,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
         const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
         const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
         tot_ta += (double)i_max / (double)CE_FFT_SIZE / lp->scs;  // T:698, the reference's two float64 divisions
+        if (a.stage_s) a.stage_s[(item * NH + h) * 2 + 1] = (double)i_max;
       }
     }
   };
@@ -859,6 +874,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
         if (L & 1) ang += (double)atan2f((float)acc[2 * L - 1], (float)acc[2 * L - 2]);
         cfo_hop = ang * hp.inv_two_pi_nsamples * plan->inv_denom_cdm;  // T:426, reciprocals from the plan (<= 1 ulp)
         if (tid == 0) misc[h] = cfo_hop;
+        if (tid == 0 && a.stage_s) a.stage_s[(item * NH + h) * 2] = cfo_hop;
       }
     }
     STAMP(2);
@@ -938,6 +954,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
       }
       __syncthreads();
     }
+    dump_stage(0, h);
 
     STAMP(4);
     // ------------------------------------------------------------ frequency smoothing (S7)
@@ -1089,6 +1106,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
       }
     }
 
+    dump_stage(1, h);
     STAMP(5);
     // ------------------------------------------------------------ residual noise, RSRP (S9, S11)
     {
@@ -1242,32 +1260,59 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   };
 
   // ce_dl_cnn.py's in-painting iterated as the reference does (masks without a closed form): the response of every
-  // (hop, layer) over the whole grid band -> scratch rows of cnn_h_stride elements (zeros outside the hop band)
+  // (hop, layer) over the hop's band -> scratch rows of cnn_h_stride elements (band-relative: element 0 is subcarrier
+  // sc0), all before the writers run.  When the rows of all (hop, layer) pairs do not fit the LDS together (many layers
+  // of wide hops, plan flag cnn_rowwise) there is ONE row: each pair is in-painted and stored in turn, every element
+  // exactly once -- by the pass of the LAST hop whose rectangle covers it (hop 2 overwrites, src/ce_dl_cnn.py:233-352), or
+  // by the zero pass when none does -- so no ordering between passes is needed.  (One call site of the in-painting, and
+  // it is inlined: an out-of-line copy would receive its LDS pointers as flat addresses.)
   const bool cnn_iterated = (FEAT & CE_FEAT_EXT) && lp->interp == CE_INTERP_CNN && !lp->cnn_comb2;
-  auto inpaint_rows = [&]() {
-    if constexpr ((FEAT & CE_FEAT_EXT) != 0) {
-      const int hs = lp->cnn_h_stride, n_sc = lp->n_sc;
+  const bool rowwise = cnn_iterated && lp->cnn_rowwise;
+  if constexpr ((FEAT & CE_FEAT_EXT) != 0) {
+    if (cnn_iterated) {
       float2* pong = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(scratch) + lp->cnn_pong_off);
       unsigned char* m_a = reinterpret_cast<unsigned char*>(scratch) + lp->cnn_m_off;
       unsigned char* m_b = m_a + ((lp->cnn_n_max + 15) & ~15);
+      auto owner = [&](int sc, int sym) __attribute__((always_inline)) -> int {
+        for (int h = NH - 1; h >= 0; --h) {
+          const CeDevHop& lh = lp->hop[h];
+          if (sym >= lh.sym0 && sym < lh.sym1 && sc >= lh.sc0 && sc < lh.sc0 + lh.n_sc_hop) return h;
+        }
+        return -1;
+      };
+      if (rowwise) {
+        for (int64_t e = tid; e < total; e += NT) {
+          const int sc = (int)(e / row), sym = (int)(e - (int64_t)sc * row) / L;
+          if (owner(sc, sym) < 0) out[e] = make_float2(0.f, 0.f);
+        }
+      }
 #pragma unroll 1
       for (int hl = 0; hl < NH * L; ++hl) {
         const int h = hl / L, l = hl - h * L;
         const CeDevHop& lh = lp->hop[h];
-        float2* row = scratch + hl * hs;
-        for (int i = tid; i < n_sc; i += NT)
-          if (i < lh.sc0 || i >= lh.sc0 + lh.n_sc_hop) row[i] = make_float2(0.f, 0.f);
         const int c = l >> 1;
         const unsigned mask12 = (unsigned)((lh.mask12 >> (16 * c)) & 0xFFFu);
         const int n_it = lh.n_sc_hop / 8 > 6 ? lh.n_sc_hop / 8 : 6;  // C:293
-        cnn_inpaint_layer(row + lh.sc0, pong, m_a, m_b, P + (h * L + l) * n_re_pad, lh.n_sc_hop, mask12, lh.dpp[c], n_it,
-                          lp->cnn_rcp, tid);
+        float2* rowp = scratch + (rowwise ? 0 : hl * lp->cnn_h_stride);
+        cnn_inpaint_layer(rowp, pong, m_a, m_b, P + (h * L + l) * n_re_pad, lh.n_sc_hop, mask12, lh.dpp[c], n_it, lp->cnn_rcp, tid);
+        if (rowwise) {
+          const int ns = lh.sym1 - lh.sym0, cnt = lh.n_sc_hop * ns;
+          for (int i = tid; i < cnt; i += NT) {
+            const int p = i / ns, sym = lh.sym0 + (i - p * ns), sc = lh.sc0 + p;
+            if (owner(sc, sym) == h) {
+              float2 val = rowp[p];
+              if (apply_rot) val = cmul(val, rot_final[sym]);
+              out[((int64_t)sc * n_sym + sym) * L + l] = val;
+            }
+          }
+          __syncthreads();
+        }
       }
       __syncthreads();
     }
-  };
+  }
 
-  if (CE_ABLATE & 8) {
+  if ((CE_ABLATE & 8) || rowwise) {
   } else if (n_sym == CE_MAX_SYMBOLS && !lp->sym_overlap) {
     // Fast writer (hop of an element decided by its symbol alone).  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
     // each of ACTIVE (a multiple of 252) threads owns ONE (symbol, layer) float4 phase for the whole item:
@@ -1294,16 +1339,20 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
     }
     float4* out4 = reinterpret_cast<float4*>(out);
     if (cnn_iterated) {
-      // in-painted response for every (hop, layer), whole band at once, then the same phase-owning store loop
+      // the in-painted rows (staged above) through the same phase-owning store loop; zeros outside a hop's band
       const int hs = lp->cnn_h_stride, n_sc = lp->n_sc;
-      inpaint_rows();
       const float2* HA = scratch + (hsel[0] * L + lsel[0]) * hs;
       const float2* HB = scratch + (hsel[1] * L + lsel[1]) * hs;
+      const int a0 = lp->hop[hsel[0]].sc0, an = lp->hop[hsel[0]].n_sc_hop;
+      const int b0 = lp->hop[hsel[1]].sc0, bn = lp->hop[hsel[1]].n_sc_hop;
       if (tid < ACTIVE) {
         float4* o = out4 + tid;
 #pragma unroll 4
         for (int s = sc_lane; s < n_sc; s += SC_STEP) {
-          const float2 ya = cmul(HA[s], rsel[0]), yb = cmul(HB[s], rsel[1]);
+          const bool ina = (unsigned)(s - a0) < (unsigned)an, inb = (unsigned)(s - b0) < (unsigned)bn;
+          const float2 ua = HA[ina ? s - a0 : 0], ub = HB[inb ? s - b0 : 0];   // always an in-range LDS address
+          const float2 za = ina ? ua : make_float2(0.f, 0.f), zb = inb ? ub : make_float2(0.f, 0.f);
+          const float2 ya = cmul(za, rsel[0]), yb = cmul(zb, rsel[1]);
           store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
           o += ACTIVE;
         }
@@ -1346,7 +1395,6 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
     // generic writer (any n_sym, hops that share symbols -- the harness's own two-hop convention,
     // scripts/validation/validate_case4.py:85-103 -- for either interpolator): decode (subcarrier, symbol, layer) per
     // element; where the hops' rectangles overlap the later hop wins (T:872-896, src/ce_dl_cnn.py:233-352)
-    if (cnn_iterated) inpaint_rows();
     auto elem = [&](int sc, int rem) -> float2 {
       const int sym = rem / L, l = rem - sym * L;
       float2 val = make_float2(0.f, 0.f);
@@ -1358,7 +1406,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
           if (lp->interp != CE_INTERP_CNN) val = interp_at(h, l, p);
           else if (lp->cnn_comb2 == 1) val = cnn2_at(h, l, p);
           else if (lp->cnn_comb2 == 2) val = cnnfp_at(h, l, p);
-          else if constexpr ((FEAT & CE_FEAT_EXT) != 0) val = scratch[(h * L + l) * lp->cnn_h_stride + sc];
+          else if constexpr ((FEAT & CE_FEAT_EXT) != 0) val = scratch[(h * L + l) * lp->cnn_h_stride + p];
           if (apply_rot) val = cmul(val, rot_final[sym]);
           break;
         }

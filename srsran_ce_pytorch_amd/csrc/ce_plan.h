@@ -47,7 +47,7 @@ struct CeDevPlan {
   int32_t n_sc, n_sym, n_layers, n_cdm, n_hops, smoothing, cfo_comp, interp;
   int32_t n_re, n_re_pad, n_pils, rc_len, ext_len, filt_lpp;
   int32_t cfo_estimated, reg_nd;      // reg_nd: DM-RS symbols per hop held in registers (0 = re-read path)
-  int32_t feat, pad0;                 // CE_FEAT_* bits the plan's kernel must carry (ce_estimate_kernel.h)
+  int32_t feat, cnn_rowwise;          // cnn_rowwise: the in-painted rows of all (hop, layer) pairs exceed the LDS: one at a time; CE_FEAT_* bits the plan's kernel must carry (ce_estimate_kernel.h)
   int32_t reg_kpt, sym_overlap;              // pilot REs per thread on the register path: smallest of 1, 2, 4, CE_KPT covering n_re; sym_overlap: the hops' fill rectangles share symbols
   int32_t scratch_bytes, wr_ch_log2;  // LDS scratch size; log2 of the writer's subcarrier chunk
   float beta_f;
@@ -60,7 +60,7 @@ struct CeDevPlan {
   double vp_mx, vp_inv_n, vp_inv_denom;  // regression constants of the n_pils-point straight-line fit (T:105-117)
   int32_t filt_windowed, pad1;        // 1: n_re <= (CE_THREADS-64)*CE_CONV_C -> sliding-window FIR
   // ce_dl_cnn.py in-painting (interp == CE_INTERP_CNN): whole-band H per (hop, layer) in the scratch
-  int32_t cnn_h_stride;               // complex elements between consecutive (hop, layer) H rows (= n_sc)
+  int32_t cnn_h_stride;               // complex elements between consecutive (hop, layer) H rows (band-relative: longest hop band, even)
   int32_t cnn_pong_off, cnn_m_off;    // byte offsets inside the scratch: second x buffer, two mask byte arrays
   int32_t cnn_n_max;                  // longest hop band (subcarriers)
   float cnn_alpha;                    // clamp(CNNSmoothingAlpha, 0, 1) (src/ce_dl_cnn.py:712-715)
@@ -81,6 +81,8 @@ struct CeKernelArgs {
   int64_t n_items;
   int32_t n_ports;
   int64_t item0, n_local;  // a launch covers work items [item0, item0 + n_local) of the n_items batch
+  float2* stage_p;             // ce_estimate_batch_stages only (else null): per-stage pilot-RE estimates, see dump_stage
+  double* stage_s;             //   ... and per-hop CFO / TA bin
   unsigned long long* stamps;  // diagnostic builds (-DCE_STAMPS) only: 16 wall-clock stamps per item; otherwise null
 };
 

@@ -15,6 +15,7 @@ PyTorch is used for device memory and streams only; all arithmetic happens in
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from collections import OrderedDict
 from typing import Any, Optional, Tuple
 
@@ -80,9 +81,9 @@ def _raise_for(code: int):
     raise RuntimeError(f"libce_hip: {msg} (code {code})")
 
 
-def build_desc(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_sym: int, device_index: int = 0,
-               interp: str = "linear"):
-    """Validate like the reference and fill a ``ce_plan_desc``.  Returns ``(desc, key, keepalive)``; needs no GPU.
+def _resolve(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_sym: int, interp: str):
+    """Validate like the reference and reduce (hop1, hop2, config) to plain values + the plan-cache key.  This is all a
+    cache hit pays for; the ctypes descriptor is only built on a miss (``_fill_desc``).
 
     Raises what the reference raises for the same inputs: ``ValueError`` for an unknown smoothing strategy
     (T:668) or a cyclic-prefix vector shorter than 14 (T:816), ``AssertionError`` for overlapping hops /
@@ -117,22 +118,28 @@ def build_desc(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_
         assert not bool(np.any(d1 & d2)), "Hops should not overlap."
         assert r1.shape == r2.shape and bool(np.all(r1 == r2)), "The DM-RS mask should be the same for the two hops."
         hops.append((hop2, d2, r2, m2))
+    geo = tuple((d, r, m, int(h.PRBstart), int(h.nPRBs), int(h.startSymbol), int(h.nAllocatedSymbols)) for h, d, r, m in hops)
+    key = (n_layers, n_prb_grid, n_sym, smoothing, cfo_comp, interp, scs, beta, alpha, mmse_tau, mmse_nsr, cp14.tobytes(),
+           tuple((d.tobytes(), r.tobytes(), r.shape, m.tobytes(), ps, npr, ss, na) for d, r, m, ps, npr, ss, na in geo))
+    vals = dict(n_layers=n_layers, n_prb_grid=n_prb_grid, n_sym=n_sym, smoothing=smoothing, cfo_comp=cfo_comp, interp=interp,
+                scs=scs, beta=beta, alpha=alpha, mmse_tau=mmse_tau, mmse_nsr=mmse_nsr, cp14=cp14, geo=geo, n_cdm=n_cdm)
+    return vals, key
 
-    key = (device_index, n_layers, n_prb_grid, n_sym, smoothing, cfo_comp, interp, scs, beta, alpha, mmse_tau, mmse_nsr, cp14.tobytes(),
-           tuple((d.tobytes(), r.tobytes(), r.shape, m.tobytes(), int(h.PRBstart), int(h.nPRBs), int(h.startSymbol),
-                  int(h.nAllocatedSymbols)) for h, d, r, m in hops))
 
+def _fill_desc(v, device_index: int):
+    """``ce_plan_desc`` from ``_resolve``'s values.  Returns ``(desc, keepalive)``."""
+    n_sym, n_prb_grid, n_cdm = v["n_sym"], v["n_prb_grid"], v["n_cdm"]
     desc = _lib.PlanDesc()
     desc.abi_version = _lib.CE_ABI_VERSION
     desc.device = device_index
-    desc.n_prb_grid, desc.n_sym, desc.n_layers, desc.n_hops = n_prb_grid, n_sym, n_layers, len(hops)
-    desc.smoothing, desc.cfo_compensate, desc.interp = _lib.SMOOTHING[smoothing], int(cfo_comp), _lib.INTERP[interp]
-    desc.scs_hz, desc.beta_dmrs, desc.cnn_smoothing_alpha = scs, beta, alpha
-    desc.mmse_delay_spread_s, desc.mmse_noise_to_signal = mmse_tau, mmse_nsr
+    desc.n_prb_grid, desc.n_sym, desc.n_layers, desc.n_hops = n_prb_grid, n_sym, v["n_layers"], len(v["geo"])
+    desc.smoothing, desc.cfo_compensate, desc.interp = _lib.SMOOTHING[v["smoothing"]], int(v["cfo_comp"]), _lib.INTERP[v["interp"]]
+    desc.scs_hz, desc.beta_dmrs, desc.cnn_smoothing_alpha = v["scs"], v["beta"], v["alpha"]
+    desc.mmse_delay_spread_s, desc.mmse_noise_to_signal = v["mmse_tau"], v["mmse_nsr"]
     for i in range(14):
-        desc.cp_ms[i] = cp14[i]
+        desc.cp_ms[i] = v["cp14"][i]
     keep = []
-    for hi, (h, d, r, m) in enumerate(hops):
+    for hi, (d, r, m, prb_start, n_prbs, start_symbol, n_alloc) in enumerate(v["geo"]):
         hd = desc.hop[hi]
         if d.size != n_sym:
             raise ValueError(f"hop {hi + 1}: DMRSsymbols has {d.size} entries, grid has {n_sym} symbols")
@@ -144,12 +151,20 @@ def build_desc(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_
             hd.dmrs_symbols[s] = int(d[s])
         for c in range(n_cdm):
             hd.re_mask[c] = int(sum(1 << rr for rr in range(12) if r[rr, c]))
-        buf = (C.c_uint8 * n_prb_grid)(*m.astype(np.uint8).tolist())
+        buf = (C.c_uint8 * n_prb_grid).from_buffer_copy(np.ascontiguousarray(m, np.uint8).tobytes())
         keep.append(buf)
         hd.mask_prbs = C.cast(buf, C.POINTER(C.c_uint8))
-        hd.prb_start, hd.n_prbs = int(h.PRBstart), int(h.nPRBs)
-        hd.start_symbol, hd.n_alloc_symbols = int(h.startSymbol), int(h.nAllocatedSymbols)
-    return desc, key, keep
+        hd.prb_start, hd.n_prbs = prb_start, n_prbs
+        hd.start_symbol, hd.n_alloc_symbols = start_symbol, n_alloc
+    return desc, keep
+
+
+def build_desc(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_sym: int, device_index: int = 0,
+               interp: str = "linear"):
+    """Validate like the reference and fill a ``ce_plan_desc``.  Returns ``(desc, key, keepalive)``; needs no GPU."""
+    vals, key = _resolve(hop1, hop2, config, beta_dmrs, n_layers, n_prb_grid, n_sym, interp)
+    desc, keep = _fill_desc(vals, device_index)
+    return desc, (device_index,) + key, keep
 
 
 def derive_host(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_sym: int, interp: str = "linear"):
@@ -169,18 +184,18 @@ def make_plan(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_s
     """Resolve (hop1, hop2, config) into a cached GPU plan (exceptions: see ``build_desc``)."""
     lib = _lib.load()
     # validation first: the reference's error cases must surface even where no GPU is visible
-    desc, key, keep = build_desc(hop1, hop2, config, beta_dmrs, n_layers, n_prb_grid, n_sym, 0, interp)
+    vals, key = _resolve(hop1, hop2, config, beta_dmrs, n_layers, n_prb_grid, n_sym, interp)
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("the estimator runs on a ROCm GPU only (no CPU fallback)")
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    desc.device = device.index
-    key = (device.index,) + key[1:]
+    key = (device.index,) + key
     plan = _PLAN_CACHE.get(key)
-    if plan is not None:
+    if plan is not None:                        # steady state: no descriptor, no ctypes buffers, no library call
         _PLAN_CACHE.move_to_end(key)
         return plan
+    desc, keep = _fill_desc(vals, device.index)
     handle = C.c_void_p()
     with torch.cuda.device(device):
         rc = lib.ce_plan_create(C.byref(desc), C.byref(handle))
@@ -248,6 +263,27 @@ def estimate_with_plan(plan: Plan, received_rg: torch.Tensor, pilots: torch.Tens
     return out
 
 
+def estimate_stages(plan: Plan, received_rg: torch.Tensor, pilots: torch.Tensor, n_hops: int):
+    """Diagnostic launch (``ce_estimate_batch_stages``): the ordinary six outputs plus
+    ``stage_estimates[B,R,2,n_hops,L,n_re]`` (pilot-RE channel estimate after LS / de-spread and after smoothing) and
+    ``stage_scalars[B,R,n_hops,2]`` (hop CFO normalised to the SCS, NaN where not estimated; TA arg-max bin)."""
+    lib = _lib.load()
+    B, R, pilots4 = _batch_args(plan, received_rg, pilots)
+    dev = plan.device
+    ch = torch.empty((B, R, plan.n_sc, plan.n_sym, plan.n_layers), dtype=torch.complex64, device=dev)
+    sc = torch.empty((5, B, R), dtype=torch.float64, device=dev)
+    st_p = torch.full((B, R, 2, n_hops, plan.n_layers, plan.n_re), float("nan"), dtype=torch.complex64, device=dev)
+    st_s = torch.full((B, R, n_hops, 2), float("nan"), dtype=torch.float64, device=dev)
+    if B * R:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.ce_estimate_batch_stages(plan._handle, received_rg.data_ptr(), _strides4(received_rg), pilots4.data_ptr(),
+                                          _strides4(pilots4), B, R, ch.data_ptr(), sc[0].data_ptr(), sc[1].data_ptr(),
+                                          sc[2].data_ptr(), sc[3].data_ptr(), sc[4].data_ptr(), st_p.data_ptr(), st_s.data_ptr(), stream)
+        if rc != 0:
+            _raise_for(rc)
+    return (ch, sc[0], sc[1], sc[2], sc[3], sc[4]), st_p, st_s
+
+
 def time_with_plan(plan: Plan, received_rg: torch.Tensor, pilots: torch.Tensor, out: tuple, warmup: int, iters: int) -> float:
     """Average launch duration in ms, HIP events on the current stream (bench.py's roofline leg)."""
     lib = _lib.load()
@@ -305,6 +341,13 @@ def srs_channel_estimator(received_rg, pilots, beta_dmrs, hop1, hop2, config, *,
     if received_rg.dim() != 2 or pilots.dim() != 3:
         raise ValueError("received_rg must be (n_sc, n_sym) and pilots (n_re, n_dmrs, n_layers)")
     in_dev, in_dtype = received_rg.device, received_rg.dtype
+    if in_dtype == torch.complex128:
+        # The reference keeps a complex128 grid in complex128 throughout (T:773-779; validate_case0.py passes one).  The HIP
+        # path computes in complex64 -- the reference's dtype for every other input -- and returns the grid cast back to
+        # complex128: ~1.7e-7 relative on the channel estimate, inside the 1e-4 bar, but narrower arithmetic
+        # than the reference's for this input, so it is said out loud rather than done silently.
+        warnings.warn("srs_channel_estimator: complex128 grid is estimated in complex64 on the GPU and cast back "
+                      "(the reference would keep float64 arithmetic; difference ~2e-7 relative)", RuntimeWarning, stacklevel=2)
     dev = in_dev if in_dev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
     rg = received_rg.to(device=dev, dtype=torch.complex64)[None, None]
     res = estimate(rg, pilots.to(dev), beta_dmrs, hop1, hop2, config, interp=interp)

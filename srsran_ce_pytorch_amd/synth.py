@@ -30,10 +30,16 @@ def normal_cp_ms(scs_hz: float, n_syms: int = 14) -> np.ndarray:
 
 
 def hop_spec(dmrs_symbols: List[int], prb_start: int, n_prbs: int, start_symbol: int = 0,
-             n_alloc: int = 14, re_masks: Optional[List[List[int]]] = None) -> Dict[str, Any]:
-    return dict(dmrs_symbols=list(dmrs_symbols), prb_start=int(prb_start), n_prbs=int(n_prbs),
-                start_symbol=int(start_symbol), n_alloc=int(n_alloc),
-                re_masks=[list(m) for m in (re_masks or [TYPE1_CDM0])])
+             n_alloc: int = 14, re_masks: Optional[List[List[int]]] = None,
+             mask_prbs: Optional[List[int]] = None) -> Dict[str, Any]:
+    """``mask_prbs``: PRB indices carrying DM-RS when they are not the contiguous run ``prb_start .. +n_prbs`` (the reference
+    extracts pilots through ``maskPRBs`` but fills the grid through ``PRBstart`` / ``nPRBs``, T:571-576 vs T:301-304)."""
+    h = dict(dmrs_symbols=list(dmrs_symbols), prb_start=int(prb_start), n_prbs=int(n_prbs),
+             start_symbol=int(start_symbol), n_alloc=int(n_alloc),
+             re_masks=[list(m) for m in (re_masks or [TYPE1_CDM0])])
+    if mask_prbs is not None:
+        h["mask_prbs"] = sorted(int(q) for q in mask_prbs)
+    return h
 
 
 def case_spec(name: str, n_prb_grid: int, hops: List[Dict[str, Any]], n_layers: int = 1,
@@ -51,7 +57,10 @@ def _hop_arrays(case: Dict[str, Any], h: Dict[str, Any]) -> SimpleNamespace:
     dm = np.zeros(n_sym, bool)
     dm[h["dmrs_symbols"]] = True
     mp = np.zeros(n_prb_grid, bool)
-    mp[h["prb_start"]: h["prb_start"] + h["n_prbs"]] = True
+    if h.get("mask_prbs") is not None:
+        mp[h["mask_prbs"]] = True
+    else:
+        mp[h["prb_start"]: h["prb_start"] + h["n_prbs"]] = True
     re_mask = np.array(h["re_masks"], bool).T.reshape(12, -1)
     return SimpleNamespace(DMRSsymbols=dm, DMRSREmask=re_mask, PRBstart=h["prb_start"], nPRBs=h["n_prbs"],
                            maskPRBs=mp, startSymbol=h["start_symbol"], nAllocatedSymbols=h["n_alloc"])

@@ -46,6 +46,8 @@ def load_fixture(name: str) -> SimpleNamespace:
         grids[:, :, cols] = gc
         fx = SimpleNamespace(case=case, variant=str(z["variant"]), pilots=z["pilots"], grids=grids,
                              ref_ch_est=z["ref_ch_est"], ref_scalars=z["ref_scalars"])
+        if "ta_bin" in z:                                   # variant "N": the reference's own arg-max bins and the power around them
+            fx.ta_bin, fx.ta_pw = z["ta_bin"], z["ta_pw"]
     hops = [S._hop_arrays(case, h) for h in case["hops"]]
     fx.hop1 = hops[0]
     fx.hop2 = hops[1] if len(hops) > 1 else S.empty_hop_arrays()
@@ -57,7 +59,30 @@ def load_fixture(name: str) -> SimpleNamespace:
     return fx
 
 
-def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what=""):
+# Near-tie class of the time alignment (fixtures of variant "N", tools/make_ta_neartie.py): where the reference's own IFFT
+# puts a neighbouring bin within this relative power of its arg-max, float32 rounding of the transform decides the bin
+# (the numpy oracle itself disagrees with torch.fft.ifft on 3 of the 42 committed items), so that neighbour is accepted too.
+TA_TIE_RATIO = 1e-5
+
+
+def ta_tie_alternatives(fx, item):
+    """TA values that differ from the reference's by ONE bin in ONE hop towards a neighbour whose power, in the
+    reference's own transform, is within TA_TIE_RATIO of the winner's -- computed with the reference's arithmetic
+    (T:698, T:918-919) so the comparison stays exact."""
+    scs, bins, n_hops = float(fx.case["scs"]), [int(b) for b in fx.ta_bin[item]], len(fx.case["hops"])
+    alts = []
+    for h in range(n_hops):
+        lo, top, hi = [float(x) for x in fx.ta_pw[item][h]]
+        for d, p in ((-1, lo), (+1, hi)):
+            if p >= (1.0 - TA_TIE_RATIO) * top and p >= 0.0:
+                ta = 0.0
+                for k in range(n_hops):
+                    ta = ta + float(bins[k] + (d if k == h else 0)) / 4096.0 / scs
+                alts.append(ta / 2.0 if n_hops == 2 else ta)
+    return alts
+
+
+def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what="", ta_alternatives=()):
     """Comparison protocol used everywhere: channel estimate error relative to the largest
     reference magnitude; scalars relative, except the residual noise whose floor is rounding
     noise of the EPRE (it is a difference of nearly equal quantities when nothing is smoothed);
@@ -71,7 +96,7 @@ def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what
     assert abs(rsrp - r_rsrp) <= tol_sc * abs(r_rsrp), f"{what}: rsrp {rsrp} vs {r_rsrp}"
     assert abs(epre - r_epre) <= tol_sc * abs(r_epre), f"{what}: epre {epre} vs {r_epre}"
     assert abs(noise - r_noise) <= tol_sc * max(abs(r_noise), 1e-2 * abs(r_epre)), f"{what}: noise {noise} vs {r_noise}"
-    assert ta == r_ta, f"{what}: time alignment {ta!r} vs {r_ta!r}"      # index work: bit-exact (T:698)
+    assert ta == r_ta or ta in ta_alternatives, f"{what}: time alignment {ta!r} vs {r_ta!r}"      # index work: bit-exact (T:698)
     if np.isnan(r_cfo):
         assert np.isnan(cfo), f"{what}: cfo should be 'not estimated'"
     else:

@@ -23,9 +23,13 @@ def test_workloads_name_baseline_configs():
 def test_cpu_baseline_leg_runs_on_a_small_sample():
     from srsran_ce_pytorch_amd import synth as S
     case = S.case_spec("tiny", 25, [S.hop_spec([2, 11], 0, 25)], seed=3)
-    for denoise in (False, True):
-        items, seconds = bench._cpu_worker((case, 2, 1, 7, "linear", denoise))
+    for flavour, denoise in (("tensorized", False), ("tensorized", True), ("baseline_loop", False), ("cnn", False)):
+        items, seconds = bench._cpu_worker((case, 2, 1, 7, flavour, denoise))
         assert items == 2 and seconds > 0
     out = bench.cpu_baseline(case, 2, target_core_seconds=0.2)
     assert out["unit"] == "slots/s" and out["kind"] == "port" and out["value"] > 0 and 1 <= out["cores"] <= 16
+    # `value` is the loop-style ce_rule_baseline port (the baseline north_star names); the tensorized port sits next to it
+    assert out["flavour"].startswith("ce_rule_baseline") and out["tensorized_value"] > out["value"] and out["config0_ms"] > 0
     json.dumps(out)
+    cnn = bench.cpu_baseline(case, 2, target_core_seconds=0.2, interp="cnn")
+    assert cnn["flavour"] == "ce_dl_cnn" and cnn["value"] > 0 and "tensorized_value" not in cnn

@@ -1,0 +1,54 @@
+"""A bounded, deterministic slice of the differential fuzzer in the GPU suite: N_CASES seeded random geometries (see
+fuzz_cases.py for what is drawn) through the HIP estimator and the CPU oracle, compared with the suite's protocol; where
+the oracle raises, the HIP boundary must raise the same exception class.  No input class is skipped."""
+import numpy as np
+import pytest
+import torch
+
+import ce_oracle as O
+import fuzz_cases as F
+from srsran_ce_pytorch_amd import estimator as E
+
+pytestmark = pytest.mark.gpu
+N_CASES = 400
+BASE_SEED = 20261004
+
+
+@pytest.mark.parametrize("idx", range(N_CASES))
+def test_fuzz_case(idx):
+    rng = np.random.default_rng([BASE_SEED, idx])
+    case, extras = F.draw(rng, 273 if idx % 8 == 0 else 106)
+    interp = extras["interp"]
+    try:
+        b = F.realize(case, extras)
+    except Exception as e:                                   # a draw the generator itself cannot lay out
+        pytest.fail(f"generator: {e!r} :: {case}")
+    want, stages, werr = [], [], None
+    try:
+        for it in range(2):
+            st = []
+            want.append(O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=interp, stages=st))
+            stages.append(st)
+    except (ValueError, AssertionError, IndexError) as e:    # IndexError: a DM-RS mask shorter than the 14 symbol start times (T:440-447)
+        werr = e
+    dev = torch.device("cuda:0")
+    g = torch.as_tensor(b.grids, device=dev)[None]
+    if not extras["layout_ref"]:
+        g = g.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
+    try:
+        out = E.estimate(g, torch.as_tensor(b.pilots, device=dev), b.beta, b.hop1, b.hop2, b.config, interp=interp)
+        torch.cuda.synchronize()
+    except NotImplementedError as e:
+        # outside the build's stated limits (include/ce_hip.h: CE_ERR_UNSUPPORTED) -- only the mmse EXTENSION has such inputs here
+        assert case["smoothing"] == "mmse", f"unsupported on a reference input: {e} :: {case} {extras}"
+        return
+    except (ValueError, AssertionError) as e:
+        assert werr is not None, f"HIP raised {e!r}, the oracle did not :: {case} {extras}"
+        assert type(e) is type(werr) or (isinstance(werr, IndexError) and isinstance(e, ValueError)), f"{e!r} vs {werr!r}"
+        return
+    assert werr is None, f"the oracle raised {werr!r}, HIP did not :: {case} {extras}"
+    ch = out[0][0].cpu().numpy()
+    sc = [t[0].cpu().numpy() if t.numel() else None for t in out[1:]]
+    for it in range(2):
+        got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], np.nan if sc[4] is None else sc[4][it]]
+        F.compare_item(case, b, ch[it], got, want[it], stages[it], f"fuzz[{idx}][{it}] {case} {extras}")

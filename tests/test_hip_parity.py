@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import check_outputs, golden_names, load_fixture
+from conftest import check_outputs, golden_names, load_fixture, ta_tie_alternatives
 
 import ce_oracle as O
 from srsran_ce_pytorch_amd import estimator as E, synth as S
@@ -47,6 +47,19 @@ def test_hip_matches_reference_fixture(name, layout):
         check_outputs(ch[it], got, fx.ref_ch_est[it], fx.ref_scalars[it], TOL_CH, TOL_SC, f"{name}[{it}]/{layout}")
 
 
+@pytest.mark.parametrize("layout", ["ref", "sym_major"])
+@pytest.mark.parametrize("name", golden_names("N"))
+def test_hip_time_alignment_near_ties(name, layout):
+    """Narrow bands whose delay sits midway between two IFFT bins (fixtures from the real reference with its own bin
+    powers, tools/make_ta_neartie.py): the HIP arg-max must be the reference's bin, or -- in one hop -- the neighbour
+    the reference's own transform puts within conftest.TA_TIE_RATIO of it.  Everything else as for any fixture."""
+    fx = load_fixture(name)
+    ch, sc = _run_items(fx, fx.grids, layout)
+    for it in range(fx.grids.shape[0]):
+        got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], np.nan if sc[4] is None else sc[4][it]]
+        check_outputs(ch[it], got, fx.ref_ch_est[it], fx.ref_scalars[it], TOL_CH, TOL_SC, f"{name}[{it}]/{layout}", ta_tie_alternatives(fx, it))
+
+
 @pytest.mark.parametrize("name", golden_names("C"))
 def test_hip_cnn_variant_matches_reference_fixture(name):
     """interp="cnn": the fixed-weight in-painting of src/ce_dl_cnn.py (fixtures from the real ce_dl_cnn)."""
@@ -67,6 +80,28 @@ def test_hip_cnn_variant_random_vs_oracle():
         ref = O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp="cnn")
         got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], sc[4][it]]
         check_outputs(ch[it], got, ref[0], list(ref[1:]), TOL_CH, TOL_SC, f"cnn_rnd[{it}]")
+
+
+SPARSE_PAIR = [[1] + [0] * 11, [0, 1] + [0] * 10]       # one pilot per PRB: the in-painting does not converge within n_sc_hop / 8 iterations
+EVERY4_PAIR = [[1, 0, 0, 0] * 3, [0, 1, 0, 0] * 3]
+CNN_ITERATED_CASES = [
+    # narrow multi-layer hops inside a 273-PRB grid: the in-painted rows are band-relative (they once spanned the grid and
+    # overflowed the LDS: a refusal the differential fuzzer found)
+    S.case_spec("cnn_it_narrow_in_273", 273, [S.hop_spec([2, 4], 142, 7, 0, 10, EVERY4_PAIR), S.hop_spec([8, 12], 30, 7, 6, 8, EVERY4_PAIR)], n_layers=3, seed=401),
+    # 4 layers of two full-band hops: eight 3276-element rows exceed the LDS -> one row at a time through the element-wise writer
+    S.case_spec("cnn_it_rowwise_273x2", 273, [S.hop_spec([2], 0, 273, 0, 7, SPARSE_PAIR), S.hop_spec([9], 0, 273, 7, 7, SPARSE_PAIR)], n_layers=4, smoothing="none", seed=402),
+    # the same shape on overlapping rectangles (hop 2 overwrites, C:233-352) and a 12-symbol grid
+    S.case_spec("cnn_it_rowwise_overlap", 273, [S.hop_spec([1], 0, 273, 0, 9, SPARSE_PAIR), S.hop_spec([10], 0, 273, 5, 7, SPARSE_PAIR)], n_layers=4, n_sym=12, seed=403),
+]
+
+
+@pytest.mark.parametrize("case", CNN_ITERATED_CASES, ids=[c["name"] for c in CNN_ITERATED_CASES])
+def test_hip_cnn_iterated_inpainting_row_layouts(case):
+    b = S.build_case(case, 1)
+    ch, sc = _run_items(b, b.grids, "sym_major", interp="cnn")
+    ref = O.srs_channel_estimator(b.grids[0], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp="cnn")
+    got = [sc[0][0], sc[1][0], sc[2][0], sc[3][0], np.nan if sc[4] is None else sc[4][0]]
+    check_outputs(ch[0], got, ref[0], [ref[1], ref[2], ref[3], ref[4], np.nan if ref[5] is None else ref[5]], TOL_CH, TOL_SC, case["name"])
 
 
 RANDOM_CASES = [
@@ -163,7 +198,8 @@ def test_shim_signature_and_types():
     same dtype/device out, 0-d float64 scalars, empty cfo with a single DM-RS symbol."""
     fx = load_fixture("case0like_3prb_4dmrs")
     rg = torch.as_tensor(fx.grids[0]).to(torch.complex128)
-    res = E.srs_channel_estimator(rg, torch.as_tensor(fx.pilots), fx.beta, fx.hop1, fx.hop2, fx.config)
+    with pytest.warns(RuntimeWarning, match="complex128 grid is estimated in complex64"):   # narrower than the reference: said out loud
+        res = E.srs_channel_estimator(rg, torch.as_tensor(fx.pilots), fx.beta, fx.hop1, fx.hop2, fx.config)
     assert res[0].dtype == torch.complex128 and res[0].device.type == "cpu" and tuple(res[0].shape) == (624, 14, 1)
     assert all(t.dtype == torch.float64 and t.dim() == 0 for t in res[1:])
     check_outputs(res[0].numpy(), [float(t) for t in res[1:]], fx.ref_ch_est[0], fx.ref_scalars[0], TOL_CH, TOL_SC, "shim")

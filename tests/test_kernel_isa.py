@@ -1,0 +1,39 @@
+"""Static checks on the gfx950 code of every estimation-kernel instantiation (cross-compiled here, no GPU needed):
+
+* no flat_load / flat_store: every LDS and global access must carry its address space.  (A lambda or helper the
+  compiler leaves out of line receives its LDS pointers as flat addresses; an index that is merely out of range then
+  becomes a memory-aperture fault instead of a harmless LDS read -- this happened once.)
+* the register-path kernels of the parity-pinned feature sets (one layer, none / mean / RC filter) keep everything in
+  registers, except the narrow two-hop shapes built for four workgroups per CU by choice (ce_min_waves)."""
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "srsran_ce_pytorch_amd" / "csrc"
+KERNEL = re.compile(r"^(_ZN12_GLOBAL__N_118ce_estimate_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E\w+):\s*;.*?\n(.*?)s_endpgm", re.S | re.M)
+
+
+def _asm(src: Path) -> str:
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}", "-S",
+           "--cuda-device-only", str(src), "-o", "-"]
+    return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+
+
+def test_no_flat_addressing_and_no_spills_on_the_pinned_register_path():
+    srcs = sorted(CSRC.glob("ce_inst_*.hip"))
+    assert len(srcs) == 6
+    with ThreadPoolExecutor(len(srcs)) as pool:
+        texts = list(pool.map(_asm, srcs))
+    seen = 0
+    for src, text in zip(srcs, texts):
+        for m in KERNEL.finditer(text):
+            L, NH, ND, KPT, FEAT = (int(x) for x in m.group(2, 3, 4, 5, 6))
+            body = m.group(7)
+            seen += 1
+            assert not re.search(r"\bflat_(load|store)", body), f"{src.name} <{L},{NH},{ND},{KPT},{FEAT}> uses flat addressing"
+            narrow_2hop_by_choice = NH == 2 and ND * KPT <= 2
+            if ND > 0 and FEAT in (0, 1) and not narrow_2hop_by_choice:
+                assert not re.search(r"\bscratch_(load|store)", body), f"{src.name} <{L},{NH},{ND},{KPT},{FEAT}> spills to scratch"
+    assert seen == 85, seen
