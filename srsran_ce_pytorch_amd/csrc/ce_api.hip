@@ -479,11 +479,13 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   I.pilot_bytes_per_slot = (int64_t)n_re * n_dmrs_total * L * 8;
 
   // IFFT twiddles exp(+j*2*pi*m/4096), float64 -> float32
-  std::vector<float2> tw(CE_FFT_SIZE + CE_MMSE_BLOCK * CE_MMSE_BLOCK);  // + W^T (Re | Im) for the mmse extension
+  std::vector<float2> tw(CE_TW_TOTAL);  // + W^T (Re | Im) for the mmse extension + the TA transform's 272, contiguous (ce_plan.h)
   for (int m = 0; m < CE_FFT_SIZE; ++m) {
     const double a = 2.0 * M_PI * (double)m / (double)CE_FFT_SIZE;
     tw[m] = make_float2((float)cos(a), (float)sin(a));
   }
+  for (int j = 0; j < 256; ++j) tw[CE_TWC_OFF + j] = tw[16 * j];
+  for (int i = 0; i < 16; ++i) tw[CE_TWC_OFF + 256 + i] = tw[i];
   if (!p->mmse_w.empty()) {
     float* wt = reinterpret_cast<float*>(tw.data() + CE_FFT_SIZE);  // [2][k][m]
     for (int part = 0; part < 2; ++part)

@@ -87,6 +87,9 @@ constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
   if (layers == 1) return nh == 2 && !(nd == 2 && kpt == 4);
   return nh == 1;
 }
+#ifndef CE_PACE_LOADS
+#define CE_PACE_LOADS 0   // experiment: wait for the pilot loads of every N-th RE before requesting the next (0: all at once)
+#endif
 #ifndef CE_RELOAD_RESID
 #define CE_RELOAD_RESID 0 // 1: the residual stage re-reads rx / pilots instead of keeping them in registers across smoothing
 #endif
@@ -310,14 +313,28 @@ __device__ __forceinline__ int64_t item_of(int64_t b, int n_ports, int64_t n_ite
   return (g * 8 + (j & 7)) * n_ports + (j >> 3);
 }
 
-// subcarrier of pilot k of CDM group c: computed for a contiguous allocation, looked up otherwise (T:572-576)
-__device__ __forceinline__ int pilot_sc(const CeDevHop& hp, const uint16_t* __restrict__ re_idx, int c, int k) {
-  if (hp.contig) {
-    const int q = hp.dpp[c] == 1 ? k : (int)__umulhi((unsigned)k, hp.div_magic[c]);
-    const int j = k - q * hp.dpp[c];
-    return 12 * (hp.prb_start + q) + (int)((hp.pos_packed[c] >> (4 * j)) & 15u);
+// subcarrier of pilot k of a CDM group: computed for a contiguous allocation, looked up otherwise (T:572-576).  The few
+// plan fields this takes are fetched ONCE into a PilotMap (scalar registers) and then used for every pilot RE of the
+// thread: read through the plan pointer inside the per-RE code they become a chain of dependent scalar loads in front of
+// every pilot load (measured: most of a 20 us start-up per workgroup under load).
+struct PilotMap {
+  int contig, dpp, prb_start, re_off;
+  unsigned magic;
+  unsigned long long pos;
+};
+__device__ __forceinline__ PilotMap pilot_map(const CeDevHop& hp, int c) {
+  PilotMap m;
+  m.contig = hp.contig; m.dpp = hp.dpp[c]; m.prb_start = hp.prb_start; m.re_off = hp.re_off[c];
+  m.magic = hp.div_magic[c]; m.pos = hp.pos_packed[c];
+  return m;
+}
+__device__ __forceinline__ int pilot_sc(const PilotMap& m, const uint16_t* __restrict__ re_idx, int k) {
+  if (m.contig) {
+    const int q = m.dpp == 1 ? k : (int)__umulhi((unsigned)k, m.magic);
+    const int j = k - q * m.dpp;
+    return 12 * (m.prb_start + q) + (int)((m.pos >> (4 * j)) & 15u);
   }
-  return re_idx[hp.re_off[c] + k];
+  return re_idx[m.re_off + k];
 }
 
 // ---- src/ce_dl_cnn.py's fixed-weight stencil (C:433-508), the reference's alternative to linear interpolation ----
@@ -573,6 +590,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   constexpr int NC = (L + 1) / 2;
   const int tid0 = threadIdx.x;
   int tid = tid0;
+#if defined(CE_STAMPS)
+  const unsigned long long t_entry = wall_clock64();   // first instruction of the workgroup (diagnostic builds)
+#endif
 
   const int n_re = plan->n_re, n_re_pad = plan->n_re_pad;
   const CeLdsLayout lay = ce_lds_layout(NH, L, n_re_pad, plan->scratch_bytes);
@@ -584,30 +604,27 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   float2* rot_pos = rot_neg + 16;                                        // [16] exp(+j ph)
   float2* tab = reinterpret_cast<float2*>(smem + lay.off_tab);           // [NH][CDM][12] {alpha, bits(r_ord)}
   double* misc = reinterpret_cast<double*>(smem + lay.off_misc);         // [0..1] cfo_hop
-  double* sst_l = misc + 4;                                              // [16] symbolStartTime
-  double* sst_dm = misc + 20;                                            // [2][14] ... at the hops' DM-RS symbols
   float2* tw256 = reinterpret_cast<float2*>(smem + lay.off_tw);          // [256] W256^j = exp(+j 2 pi j / 256)
   float2* tw16 = tw256 + 256;                                            // [16]  W4096^i
-  double* rcz = reinterpret_cast<double*>(smem + lay.off_rcz);           // zero-padded RC taps
-  // LDS copy of the plan: every stage after the first barrier reads its parameters from here.  Scalar loads from
-  // global memory queue behind the chip-wide store stream (microseconds each under load); LDS reads do not.
+  // LDS copy of the plan: every stage after the first barrier reads its parameters from here (also the zero-padded RC
+  // taps, the symbol start times and the interpolation anchors: they are fields of the plan).  Scalar loads from global
+  // memory queue behind the chip-wide store stream (microseconds each under load); LDS reads do not.
+  //
+  // Everything a workgroup fetches before it can start -- this copy, the TA twiddles, the item's pilots -- is REQUESTED
+  // here, back to back, and only then waited for: one memory round trip.  (Copy loops that load, wait and store one
+  // after the other cost a round trip each; under full load that preamble measured 20 us of a 58 us workgroup.)
   const CeDevPlan* lp = reinterpret_cast<const CeDevPlan*>(smem + lay.off_plan);
-  for (int i = tid; i < (int)(sizeof(CeDevPlan) / 4); i += NT)
-    reinterpret_cast<uint32_t*>(smem + lay.off_plan)[i] = reinterpret_cast<const uint32_t*>(plan)[i];
+  constexpr int PLAN4 = (int)(sizeof(CeDevPlan) / 16), TW4 = (256 + 16) / 2;
+  static_assert(sizeof(CeDevPlan) % 16 == 0 && PLAN4 <= NT && TW4 <= NT, "one float4 per thread covers the plan and the twiddles");
+  float4 plan_v = make_float4(0.f, 0.f, 0.f, 0.f), tw_v = plan_v;
+  if (tid < PLAN4) plan_v = reinterpret_cast<const float4*>(plan)[tid];
+  if (tid < TW4) tw_v = reinterpret_cast<const float4*>(tw + CE_TWC_OFF)[tid];   // W256^j (j < 256) then W4096^i (i < 16), contiguous
+  const double* rcz = lp->rcz;                                           // zero-padded RC taps
+  const double* sst_l = lp->sst;                                         // [14] symbolStartTime
+  const double* sst_dm = &lp->sst_dmrs[0][0];                            // [2][14] ... at the hops' DM-RS symbols
 
   const float beta_f = plan->beta_f;
   const bool cfo_comp = plan->cfo_comp != 0;
-
-  // twiddles for the TA transform -> LDS (global loads issued now, consumed many barriers later)
-  for (int i = tid; i < 256 + 16; i += NT) tw256[i] = i < 256 ? tw[16 * i] : tw[i - 256];
-  for (int i = tid; i < CE_RCZ_LEN; i += NT) rcz[i] = plan->rcz[i];
-  if (tid < CE_MAX_SYMBOLS) sst_l[tid] = plan->sst[tid];
-  if (tid >= 64 && tid < 64 + CE_MAX_HOPS * CE_MAX_SYMBOLS) sst_dm[tid - 64] = (&plan->sst_dmrs[0][0])[tid - 64];
-  // interpolation tables -> LDS (first read after several barriers)
-  for (int i = tid; i < NH * CE_MAX_CDM * 12; i += NT) {
-    const int h = i / (CE_MAX_CDM * 12), c = (i / 12) % CE_MAX_CDM, r = i % 12;
-    tab[i] = make_float2(plan->hop[h].alpha[c][r], __int_as_float(plan->hop[h].r_ord[c][r]));
-  }
 
   // Register path: received pilot REs and DM-RS symbols of (item, hop), KPT per thread.
   float2 xr[REG ? KPT * ND : 1];
@@ -616,16 +633,54 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   // them, so they come from L2
   constexpr bool PREG = ce_pilots_in_regs(NH, ND, KPT);
   float2 pr[PREG ? KPT * ND * L : 1];
-  auto load_hop = [&](int64_t it, int h) {
+  auto load_hop = [&](int64_t it, int h) __attribute__((always_inline)) {
     if constexpr (REG) {
       const CeDevHop& hp = plan->hop[h];
       const int64_t sl = it / a.n_ports;
       const float2* rx = a.rx + sl * a.rs_b + (it - sl * a.n_ports) * a.rs_r;
       const float2* pil = a.pil + sl * a.ps_b;
+      // every plan field the loads need, fetched once up front (one scalar-load round trip for the whole hop)
+      PilotMap pm = pilot_map(hp, 0);
+      int dsym[ND], psym0 = hp.pil_sym0;
+#pragma unroll
+      for (int s = 0; s < ND; ++s) dsym[s] = hp.dmrs_sym[s];
+      // one point where all of them must be present: the compiler then requests them together and waits once (left to
+      // itself it sinks each scalar load to its use, behind a branch, and pays a round trip per field)
+      asm volatile("" : "+s"(pm.contig), "+s"(pm.dpp), "+s"(pm.prb_start), "+s"(pm.re_off), "+s"(pm.magic), "+s"(pm.pos), "+s"(psym0));
+#pragma unroll
+      for (int s = 0; s < ND; ++s) asm volatile("" : "+s"(dsym[s]));
+      const float2* rx_s[ND];
+      const float2* pil_s[ND];
+#pragma unroll
+      for (int s = 0; s < ND; ++s) {
+        rx_s[s] = rx + dsym[s] * a.rs_sym;
+        pil_s[s] = pil + (psym0 + s) * a.ps_sym;
+      }
+      // Subcarrier offsets of this thread's pilot REs first -- for a scattered PRB mask that is a batch of table reads
+      // with ONE wait, under a branch that is uniform for the launch (left inside the per-RE code the lookup is
+      // speculated and its wait serialises the pilot loads of consecutive REs) -- then all pilot loads back to back and
+      // unconditional: a thread past the band's end reads pilot 0 again and clears the value afterwards (`finish_hop`),
+      // because an if / else around each load makes the compiler wait for the load before the else side's zero fill.
+      unsigned xoff[KPT];
+      if (pm.contig) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+          const int k = tid + i * NT, kk = k < n_re ? k : 0;
+          const int q = pm.dpp == 1 ? kk : (int)__umulhi((unsigned)kk, pm.magic);
+          const int j = kk - q * pm.dpp;
+          xoff[i] = (unsigned)(12 * (pm.prb_start + q) + (int)((pm.pos >> (4 * j)) & 15u)) * (unsigned)a.rs_sc;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+          const int k = tid + i * NT;
+          xoff[i] = (unsigned)re_idx[pm.re_off + (k < n_re ? k : 0)] * (unsigned)a.rs_sc;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < KPT; ++i) {
         const int k = tid + i * NT;
-        if (k < n_re && (CE_ABLATE & 32)) {  // timing experiment: no global reads at all
+        if (CE_ABLATE & 32) {  // timing experiment: no global reads at all
 #pragma unroll
           for (int s = 0; s < ND; ++s) {
             xr[i * ND + s] = make_float2(1.f + k * 1e-3f, 0.5f);
@@ -633,22 +688,29 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
             for (int l = 0; l < L; ++l)
               if constexpr (PREG) pr[(i * ND + s) * L + l] = make_float2(0.7071f, -0.7071f);
           }
-        } else if (k < n_re) {
+        } else {
           // uniform 64-bit base (SGPR pair) + 32-bit per-thread offset: one address VGPR per pilot RE
           // instead of two per load (the host checks the offsets fit 32 bits)
-          const unsigned xo = (unsigned)pilot_sc(hp, re_idx, 0, k) * (unsigned)a.rs_sc;
-          const unsigned po = (unsigned)k * (unsigned)a.ps_re;
+          const unsigned xo = xoff[i];
+          const unsigned po = (unsigned)(k < n_re ? k : 0) * (unsigned)a.ps_re;
 #pragma unroll
           for (int s = 0; s < ND; ++s) {
-            const float2* rx_s = rx + hp.dmrs_sym[s] * a.rs_sym;
-            xr[i * ND + s] = rx_s[xo];
+            xr[i * ND + s] = rx_s[s][xo];
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-              const float2* pil_sl = pil + (hp.pil_sym0 + s) * a.ps_sym + l * a.ps_l;
-              if constexpr (PREG) pr[(i * ND + s) * L + l] = pil_sl[po];
-            }
+            for (int l = 0; l < L; ++l)
+              if constexpr (PREG) pr[(i * ND + s) * L + l] = (pil_s[s] + l * a.ps_l)[po];
           }
-        } else {
+          if (CE_PACE_LOADS > 0 && (i + 1) % CE_PACE_LOADS == 0 && i + 1 < KPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+    }
+  };
+  // second half of load_hop, placed where the data is first needed: pilot REs past the end of the band count as zero
+  auto finish_hop = [&]() __attribute__((always_inline)) {
+    if constexpr (REG) {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (tid + i * NT >= n_re) {
 #pragma unroll
           for (int s = 0; s < ND; ++s) {
             xr[i * ND + s] = make_float2(0.f, 0.f);
@@ -662,18 +724,25 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   };
   if (blockIdx.x >= a.n_local) return;  // the grid is exactly n_local workgroups
   const int64_t item = a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local);
+#if defined(CE_PLAN_FIRST)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // experiment: the copies' round trip completes before the pilots are requested
+#endif
   load_hop(item, 0);
+  // the copies' LDS stores come after the pilot requests, so waiting for their data does not delay those
+  if (tid < PLAN4) reinterpret_cast<float4*>(smem + lay.off_plan)[tid] = plan_v;
+  if (tid < TW4) reinterpret_cast<float4*>(tw256)[tid] = tw_v;
   const int64_t slot = item / a.n_ports;
   const int port = (int)(item - slot * a.n_ports);
   const float2* rx = a.rx + slot * a.rs_b + port * a.rs_r;
   const float2* pil = a.pil + slot * a.ps_b;
-  auto pilot_of = [&](const CeDevHop& hh, int i, int s, int l) -> float2 {  // DM-RS symbol of pilot RE tid + i*NT (register path)
+  int pil_sym0_h = 0;  // first column of the current hop along the pilots' symbol axis (set once per hop)
+  auto pilot_of = [&](const CeDevHop&, int i, int s, int l) __attribute__((always_inline)) -> float2 {  // DM-RS symbol of pilot RE tid + i*NT (register path)
     if constexpr (PREG) {
       return pr[(i * ND + s) * L + l];
     } else {
       const int k = tid + i * NT;
       if (k >= n_re) return make_float2(0.f, 0.f);
-      const float2* pil_sl = pil + (hh.pil_sym0 + s) * a.ps_sym + l * a.ps_l;
+      const float2* pil_sl = pil + (pil_sym0_h + s) * a.ps_sym + l * a.ps_l;
       return pil_sl[(unsigned)k * (unsigned)a.ps_re];
     }
   };
@@ -801,6 +870,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   double tot_epre = 0.0, tot_noise = 0.0, tot_rsrp = 0.0;
   STAMP(0);
   STAMP_HWID(12);
+#if defined(CE_STAMPS)
+  if (threadIdx.x == 0 && a.stamps) a.stamps[item * 16 + 13] = t_entry;
+#endif
 
 #pragma unroll 1
   for (int h = 0; h < NH; ++h) {
@@ -811,6 +883,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
     const float n_dmrs_f = (float)n_dmrs;
     const bool has_cfo = REG ? (ND >= 2) : (hp.has_cfo != 0);
     if (h > 0) load_hop(item, h);
+    finish_hop();
+    pil_sym0_h = hp.pil_sym0;
     if (NH > 1) {
       // Everything a stage derives from the thread index and the plan is loop-invariant; left alone, the compiler
       // hoists all of it out of the hop loop and keeps it live across every stage.  An opaque copy of the thread index
@@ -849,10 +923,13 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
       } else if constexpr (!REG) {
         const int64_t o0 = hp.dmrs_sym[0] * a.rs_sym, o1 = hp.dmrs_sym[1] * a.rs_sym;
         const int64_t p0 = hp.pil_sym0 * a.ps_sym, p1 = (hp.pil_sym0 + 1) * a.ps_sym;
+        PilotMap pmc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) pmc[c] = pilot_map(hp, c);
         for (int k = tid; k < n_re; k += NT) {
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
-            const int64_t sc = pilot_sc(hp, re_idx, c, k);
+            const int64_t sc = pilot_sc(pmc[c], re_idx, k);
             const float2 x0 = rx[sc * a.rs_sc + o0], x1 = rx[sc * a.rs_sc + o1];
 #pragma unroll
             for (int l = 2 * c; l < 2 * c + 2 && l < L; ++l) {
@@ -920,10 +997,13 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
         }
       }
     } else {
+      PilotMap pmc[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) pmc[c] = pilot_map(lh, c);
       for (int k = tid; k < n_re; k += NT) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          const int64_t sc = pilot_sc(hp, re_idx, c, k);
+          const int64_t sc = pilot_sc(pmc[c], re_idx, k);
           float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
           for (int s = 0; s < n_dmrs; ++s) {
             const float2 x = rx[sc * a.rs_sc + lh.dmrs_sym[s] * a.rs_sym];
@@ -1134,6 +1214,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
           }
         }
       } else {
+        PilotMap pmc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) pmc[c] = pilot_map(lh, c);
         for (int k = tid; k < ((CE_ABLATE & 4) ? 0 : n_re); k += NT) {
 #pragma unroll
           for (int l = 0; l < L; ++l) {
@@ -1142,7 +1225,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
           }
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
-            const int64_t sc = pilot_sc(hp, re_idx, c, k);
+            const int64_t sc = pilot_sc(pmc[c], re_idx, k);
             const float2 h0 = Ph[(2 * c) * n_re_pad + k];
             const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * n_re_pad + k] : make_float2(0.f, 0.f);
             for (int s = 0; s < n_dmrs; ++s) {
@@ -1170,6 +1253,11 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   STAMP(7);
   // ---------------------------------------------------------------- slot-level epilogue (T:898-937)
   const bool apply_rot = cfo_comp && lp->cfo_estimated && !(CE_ABLATE & 16);
+  // interpolation anchors {alpha, bits(r_ord)} packed for one 8-byte LDS read in the writers (T:325-337)
+  for (int i = tid; i < NH * CE_MAX_CDM * 12; i += NT) {
+    const int h = i / (CE_MAX_CDM * 12), c = (i / 12) % CE_MAX_CDM, r = i % 12;
+    tab[i] = make_float2(lp->hop[h].alpha[c][r], __int_as_float(lp->hop[h].r_ord[c][r]));
+  }
   if (tid < 16) {
     double cfo = 0.0;  // running mean over the hops that estimated one (T:605-609)
     bool have = false;

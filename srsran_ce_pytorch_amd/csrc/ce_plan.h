@@ -15,6 +15,10 @@
 #define CE_CONV_C 9         // consecutive RC-FIR outputs per thread (sliding window), conv threads = CE_THREADS - 64
 #define CE_RCZ_LEN (CE_MAX_RC_TAPS + 2 * (CE_CONV_C - 1))
 #define CE_TA_ROW 272       // 16 x 17 complex per residue block (padded against LDS bank conflicts)
+// the twiddle buffer (complex64 elements): exp(+j 2 pi m / 4096), m < 4096 | mmse W^T (extension) | the 272 twiddles the
+// TA transform uses, contiguous: W256^j = tw[16 j] (j < 256), then W4096^i = tw[i] (i < 16)
+#define CE_TWC_OFF (CE_FFT_SIZE + CE_MMSE_BLOCK * CE_MMSE_BLOCK)
+#define CE_TW_TOTAL (CE_TWC_OFF + 256 + 16)
 
 struct CeDevHop {
   int32_t n_dmrs;                     // DM-RS symbols in the hop
@@ -43,7 +47,7 @@ struct CeDevHop {
   uint32_t pad1;
 };
 
-struct CeDevPlan {
+struct alignas(16) CeDevPlan {
   int32_t n_sc, n_sym, n_layers, n_cdm, n_hops, smoothing, cfo_comp, interp;
   int32_t n_re, n_re_pad, n_pils, rc_len, ext_len, filt_lpp;
   int32_t cfo_estimated, reg_nd;      // reg_nd: DM-RS symbols per hop held in registers (0 = re-read path)
@@ -99,9 +103,9 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
   l.off_red = o;      o += (CE_THREADS / 64) * 16 * 8;           // 16 doubles per wave
   l.off_rot = o;      o += (1 + 2 * CE_MAX_HOPS) * 16 * 8;       // final, per-hop -/+ phasors, 16 float2 each
   l.off_tab = o;      o += CE_MAX_HOPS * CE_MAX_CDM * 12 * 8;    // {alpha, r_ord} pairs
-  l.off_misc = o;     o += 56 * 8;                               // doubles: cfo_hop[2], pad[2], sst[16], sst_dmrs[2][14], TA arg-max keys[8]
+  l.off_misc = o;     o += 56 * 8;                               // doubles: cfo_hop[2], ..., TA arg-max keys[8] at [48]
   l.off_tw = o;       o += (256 + 16) * 8;                       // W256^j, W4096^i for the TA transform
-  l.off_rcz = o;      o += ((CE_RCZ_LEN + 1) & ~1) * 8;          // zero-padded RC taps (float64)
+  l.off_rcz = o;                                                 // (the RC taps are read from the LDS plan copy)
   l.off_plan = o;     o += (int)((sizeof(CeDevPlan) + 15) & ~15); // LDS copy of the plan (no scalar loads from global later)
   l.total = (o + 15) & ~15;
   return l;

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Program for rocprofv3 to wrap (GPU box): a few launches of each named geometry, in a fixed order.
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2_geo_trace -- python3 tools/prof_geometries.py
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r2_geo_fetch -- python3 tools/prof_geometries.py
+    ... (one --pmc pass per counter group: tools/distill_geometry_counters.py lists them)
+
+Writes gpurun_out/prof_geometries_order.json: for every geometry its name, kernel launches, work items and
+algorithmic bytes per launch, so the distiller can attribute the dispatches (in order) of the counter CSVs."""
+import json, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "tools")]
+import torch
+from srsran_ce_pytorch_amd import estimator as E, synth as S
+from perf_cases import CASES
+
+WANT = ["L1 2dmrs filter (register path)", "L1 2dmrs none", "L1 2 hops x 2dmrs 200 PRB", "L1 2 hops x 3dmrs 200 PRB",
+        "L1 2 hops x 1dmrs 12 PRB in 52", "L1 25 PRB in 52", "L4 2 hops x 2dmrs 136 PRB", "L1 cnn type-2 100 PRB (iterated)"]
+LAUNCHES = 4
+dev = torch.device("cuda:0")
+order = []
+by_name = {n: (c, i) for n, c, i in CASES}
+
+
+def run(tag, case, interp, slots, ports, ref_layout=False):
+    h1, h2, cfg = S.numpy_hops(case)
+    plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], 14, dev, interp)
+    rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
+    if ref_layout:
+        rx = rx.contiguous()
+    out = E.estimate_with_plan(plan, rx, pil)
+    for _ in range(LAUNCHES - 1):
+        E.estimate_with_plan(plan, rx, pil, out)
+    torch.cuda.synchronize()
+    order.append(dict(name=tag, launches=LAUNCHES, items=slots * ports, lds_bytes=plan.lds_bytes,
+                      alg_bytes_per_launch=slots * (ports * plan.alg_bytes_per_item + plan.pilot_bytes_per_slot)))
+    del rx, pil, out
+
+
+for name in WANT:
+    case, interp = by_name[name]
+    run(name, case, interp, 8192, 4)
+case, interp = by_name["L1 2dmrs none"]
+run("configs[1]: L1 2dmrs none, 1024 slots x 1 Rx", case, interp, 1024, 1)
+case, interp = by_name["L1 2dmrs filter (register path)"]
+run("headline in the reference [sc][sym] layout", case, interp, 8192, 4, ref_layout=True)
+(ROOT / "gpurun_out").mkdir(exist_ok=True)
+(ROOT / "gpurun_out" / "prof_geometries_order.json").write_text(json.dumps(order, indent=1))
+print("\n".join(f"{o['name']}: {o['launches']} launches" for o in order))

@@ -43,6 +43,7 @@ for name, case, interp in CASES:
         d = np.diff(t[:, :12], axis=1)
         print(f"--- {name}: {n} items: median us per stage (item total {np.median(t[:,11]-t[:,0]):.1f} us, to end of writer {np.median(t[:,10]-t[:,0]):.1f}; kernel span {(t[:,11].max()-t[:,0].min()):.0f} us)")
         print("  ".join(f"{nm}={np.median(d[:, i]):.2f}" for i, nm in enumerate(names)), flush=True)
+        print(f"  kernel entry -> first stage stamp (arguments, plan / twiddle / table copies to LDS, pilot loads issued): median {np.median(t[:, 0] - t[:, 13]):.2f} us, p95 {np.percentile(t[:, 0] - t[:, 13], 95):.2f} us")
         # residency: which CU each workgroup ran on (HW_ID bits 8-15: CU / SH / SE, XCC_ID), how many were resident
         # on a CU on average, and how long a CU waited between one workgroup's last stamp and the next one's first
         hw = st.cpu().numpy()[:, 12]
@@ -51,8 +52,8 @@ for name, case, interp in CASES:
         res, gaps = [], []
         for c in np.unique(cu):
             m = cu == c
-            s0, e0 = np.sort(t[m, 0]), np.sort(t[m, 11])
-            res.append((t[m, 11] - t[m, 0]).sum() / span)
+            s0, e0 = np.sort(t[m, 13]), np.sort(t[m, 11])
+            res.append((t[m, 11] - t[m, 13]).sum() / span)
             k = int(round(res[-1] + 0.5)) or 1
             if len(s0) > 2 * k:
                 # with k slots busy, the i-th start follows the (i-k)-th end
