@@ -42,6 +42,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_MIN_WAVES_LIGHT
 #define CE_MIN_WAVES_LIGHT 3   // the same for single-hop register-path kernels built without the FIR ("none" / "mean" smoothing)
 #endif
+#ifndef CE_MW5_LIMIT
+#define CE_MW5_LIMIT 0   // single hop: up to this many pilot REs x symbols per thread, 5 workgroups per CU (<= 96 VGPRs)
+#endif
 #ifndef CE_MW4_LIMIT
 #define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
 #endif
@@ -66,7 +69,7 @@ constexpr int CE_FEAT_FIR = 1, CE_FEAT_EXT = 2;
 constexpr int ce_min_waves(int nh, int nd, int kpt, int feat) {
   const int n = nd * kpt;
   if (nd == 0) return CE_MIN_WAVES;
-  if (nh == 1) return n <= CE_MW4_LIMIT ? 4 : n <= 14 ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
+  if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= 14 ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
   return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
 }
 constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
@@ -87,8 +90,8 @@ constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
   if (layers == 1) return nh == 2 && !(nd == 2 && kpt == 4);
   return nh == 1;
 }
-#ifndef CE_PACE_LOADS
-#define CE_PACE_LOADS 0   // experiment: wait for the pilot loads of every N-th RE before requesting the next (0: all at once)
+#ifndef CE_PF1_LIMIT
+#define CE_PF1_LIMIT 4    // two hops: up to this many pilot REs x symbols per thread, hop 2's pilots are prefetched with hop 1's
 #endif
 #ifndef CE_RELOAD_RESID
 #define CE_RELOAD_RESID 0 // 1: the residual stage re-reads rx / pilots instead of keeping them in registers across smoothing
@@ -241,6 +244,20 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
   for (int i = 0; i < 16; ++i) v[i] = o[i];
 }
 
+// 16-lane (one DPP row) helpers for the band-edge fits: VALU cross-lane moves instead of ds_bpermute round trips
+// (a __shfl on a double is two of those, ~100+ cycles each, and the fit chains about twenty of them).
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {  // lane j of a row receives lane j - N of the same row, 0 for j < N
+  return dpp_f64<0x110 + N, 0xF>(v);
+}
+__device__ __forceinline__ double row_sum(double v) {  // every lane of a row receives the sum over its 16 lanes
+  v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_f64<0x140, 0xF>(v);  // row_mirror
+  return v;
+}
+
 // One 16-lane group per band edge: straight-line fit of modulus and unwrapped phase of the n_pils pilots
 // next to the edge, extrapolated n_pils positions outwards (T:69-140, T:35-66).  `out(e)` receives the
 // virtual pilot at distance e+1 from the band (e = 0 is adjacent to the first / last real pilot).
@@ -260,7 +277,7 @@ __device__ __forceinline__ void virtual_pilots(const float2* Pl, int n_re, int n
     outi = amp * (double)sn;
   } else {
     // unwrap: per-gap correction then inclusive prefix sum over the 16-lane group
-    const double prev = __shfl_up(ang, 1, 16);
+    const double prev = row_shr<1>(ang);
     double corr = 0.0;
     if (j >= 1 && j < n_pils) {
       const double dd = ang - prev;
@@ -270,22 +287,18 @@ __device__ __forceinline__ void virtual_pilots(const float2* Pl, int n_re, int n
       if (ddmod == -PI && dd > 0.0) ddmod += 2.0 * PI;
       corr = fabs(dd) < PI ? 0.0 : ddmod - dd;
     }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      const double t = __shfl_up(corr, o, 16);
-      if (j >= o) corr += t;
-    }
+    corr += row_shr<1>(corr);   // inclusive prefix sum over the row (lanes below the shift receive 0)
+    corr += row_shr<2>(corr);
+    corr += row_shr<4>(corr);
+    corr += row_shr<8>(corr);
     const double ph = ang + corr;
     const bool in = j < n_pils;
     const double x = (double)j;
     double sa = in ? amp : 0.0, sxa = in ? x * amp : 0.0, sp = in ? ph : 0.0, sxp = in ? x * ph : 0.0;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      sa += __shfl_xor(sa, o, 16);
-      sxa += __shfl_xor(sxa, o, 16);
-      sp += __shfl_xor(sp, o, 16);
-      sxp += __shfl_xor(sxp, o, 16);
-    }
+    sa = row_sum(sa);
+    sxa = row_sum(sxa);
+    sp = row_sum(sp);
+    sxp = row_sum(sxp);
     const double n = (double)n_pils;
     const double ma = sa * inv_n, mp = sp * inv_n;
     const double a_amp = (sxa - n * mx * ma) * inv_denom, b_amp = ma - a_amp * mx;
@@ -633,7 +646,12 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   // them, so they come from L2
   constexpr bool PREG = ce_pilots_in_regs(NH, ND, KPT);
   float2 pr[PREG ? KPT * ND * L : 1];
-  auto load_hop = [&](int64_t it, int h) __attribute__((always_inline)) {
+  // Two hops on the narrow tiers: the second hop's pilots are requested together with the first's (a few registers
+  // more) instead of after the first hop's stages -- one memory round trip less in a latency-bound item.
+  constexpr bool PF1 = REG && NH == 2 && KPT * ND <= CE_PF1_LIMIT;
+  float2 xr1[PF1 ? KPT * ND : 1];
+  float2 pr1[PF1 && PREG ? KPT * ND * L : 1];
+  auto load_hop = [&](int64_t it, int h, auto& xr, auto& pr) __attribute__((always_inline)) {
     if constexpr (REG) {
       const CeDevHop& hp = plan->hop[h];
       const int64_t sl = it / a.n_ports;
@@ -700,7 +718,6 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
             for (int l = 0; l < L; ++l)
               if constexpr (PREG) pr[(i * ND + s) * L + l] = (pil_s[s] + l * a.ps_l)[po];
           }
-          if (CE_PACE_LOADS > 0 && (i + 1) % CE_PACE_LOADS == 0 && i + 1 < KPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
     }
@@ -724,10 +741,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   };
   if (blockIdx.x >= a.n_local) return;  // the grid is exactly n_local workgroups
   const int64_t item = a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local);
-#if defined(CE_PLAN_FIRST)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // experiment: the copies' round trip completes before the pilots are requested
-#endif
-  load_hop(item, 0);
+  load_hop(item, 0, xr, pr);
+  if constexpr (PF1) load_hop(item, 1, xr1, pr1);  // hop 2's pilots ride the same round trip (narrow tiers: few registers)
   // the copies' LDS stores come after the pilot requests, so waiting for their data does not delay those
   if (tid < PLAN4) reinterpret_cast<float4*>(smem + lay.off_plan)[tid] = plan_v;
   if (tid < TW4) reinterpret_cast<float4*>(tw256)[tid] = tw_v;
@@ -780,7 +795,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
       auto bin_power = [&](int k) -> float {
         const int q = k & 255, off = (q & 15) * 17 + (q >> 4);
         float2 acc = make_float2(0.f, 0.f);
-        for (int i = 0; i < nres; ++i) {
+#pragma unroll 4
+        for (int i = 0; i < nres; ++i) {  // (same order of additions whatever the unrolling: bit-identical)
           const int m = ((int)((res_packed >> (4 * i)) & 15u) * k) & (CE_FFT_SIZE - 1);  // W4096^(r k)
           acc = cadd(acc, cmul(cmul(tw256[m >> 4], tw16[m & 15]), scratch[i * CE_TA_ROW + off]));
         }
@@ -882,7 +898,16 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
     const int n_dmrs = REG ? ND : hp.n_dmrs;
     const float n_dmrs_f = (float)n_dmrs;
     const bool has_cfo = REG ? (ND >= 2) : (hp.has_cfo != 0);
-    if (h > 0) load_hop(item, h);
+    if (h > 0) {
+      if constexpr (PF1) {
+#pragma unroll
+        for (int i = 0; i < (REG ? KPT * ND : 1); ++i) xr[i] = xr1[i];
+#pragma unroll
+        for (int i = 0; i < (PREG ? KPT * ND * L : 1); ++i) pr[i] = pr1[i];
+      } else {
+        load_hop(item, h, xr, pr);
+      }
+    }
     finish_hop();
     pil_sym0_h = hp.pil_sym0;
     if (NH > 1) {

@@ -9,6 +9,8 @@ Passes (each its own rocprofv3 run; --pmc never combined with tracing):
 Dispatches of ce_estimate_kernel are attributed to geometries by order (gpurun_out/prof_geometries_order.json)."""
 import csv, glob, json, os, statistics as st, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
+OUT = "gpurun_out/distilled"   # gpurun merges only gpurun_out/ back; copy the files into profiles/ afterwards
+os.makedirs(OUT, exist_ok=True)
 order = json.load(open("gpurun_out/prof_geometries_order.json"))
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 
@@ -67,7 +69,7 @@ for r_ in res:
         if r_.get("GRBM_GUI_ACTIVE"):
             # waves resident per CU on average: wave-cycles / (kernel cycles x 256 CUs); GRBM_GUI_ACTIVE is summed over the 8 XCDs
             r_["resident_waves_per_cu"] = 4.0 * wc / (r_["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
-json.dump(dict(passes=__doc__.split("Passes")[1].strip().splitlines()[:5], geometries=res), open(f"profiles/{tag}_geometry_counters.json", "w"), indent=1)
+json.dump(dict(passes=__doc__.split("Passes")[1].strip().splitlines()[:5], geometries=res), open(f"{OUT}/{tag}_geometry_counters.json", "w"), indent=1)
 for r_ in res:
     print(f"{r_['name'][:46]:46s} {r_['kernel_us_median']:8.1f} us  alg {r_['alg_GBps']:6.0f} GB/s ({r_['alg_frac_of_8TBps']:.3f})  traffic x{r_['traffic_over_algorithmic']:.2f}"
           f"  parked {r_.get('wave_parked_frac', float('nan')):.2f} stall {r_.get('wave_issue_stall_frac', float('nan')):.2f} issuing {r_.get('wave_issuing_frac', float('nan')):.2f}"

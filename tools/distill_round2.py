@@ -3,10 +3,12 @@
 tools/gpu_profile_round.sh) -> profiles/round2_{summary.json,kernel_stats.csv,bench_line.json}."""
 import csv, glob, json, os, re, statistics as st, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
+OUT = "gpurun_out/distilled"   # gpurun merges only gpurun_out/ back; copy the files into profiles/ afterwards
+os.makedirs(OUT, exist_ok=True)
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 ks = list(csv.DictReader(open(newest("gpurun_out/r2_bench_trace/*/*_kernel_stats.csv"))))
-os.makedirs("profiles", exist_ok=True)
-with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
+
+with open(f"{OUT}/{tag}_kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(ks[0].keys())
     for r in ks[:12]:
         r = dict(r); r["Name"] = r["Name"][:160]; w.writerow(r.values())
@@ -52,7 +54,7 @@ if sq.get("SQ_WAVE_CYCLES"):
 out["sq"] = sq
 # same-lease: plain bench line and the access-pattern micro-benchmark
 line = [l for l in open("gpurun_out/r2_bench_same_lease.log") if l.startswith("{")][-1]
-open(f"profiles/{tag}_bench_line.json", "w").write(line)
+open(f"{OUT}/{tag}_bench_line.json", "w").write(line)
 bl = json.loads(line)
 out["same_lease_bench"] = {"ms_per_step": bl["ms_per_step"], "kernel_ms": bl["roofline"]["kernel_ms"], "roofline_frac": bl["roofline"]["frac"],
                            "secondary": [(s["workload"], s["rx_layout"], round(s["ms_per_step"], 4), round(s["roofline"]["frac"], 4)) for s in bl.get("secondary", [])],
@@ -63,5 +65,5 @@ for l in open("gpurun_out/r2_rwmix.log"):
     if m:
         rw[m.group(1).strip()] = {"ms": float(m.group(2)), "GBps": float(m.group(3)), "of": m.group(4).strip()}
 out["same_lease_rwmix"] = rw
-json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+json.dump(out, open(f"{OUT}/{tag}_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
