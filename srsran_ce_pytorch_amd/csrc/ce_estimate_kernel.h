@@ -81,14 +81,15 @@ constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
 #ifndef CE_TA_LATE
 #define CE_TA_LATE -1   // -1: per-shape policy below; 0 / 1: force (A/B builds)
 #endif
-// Policy from a same-box A/B of both placements over tools/perf_cases.py (profiles/round2_ta_placement_ab.txt): late wins
-// 4-8 % where two hops run the estimation twice per item (one layer) and 1-2 % for 2-4 layers of one hop; early wins
-// 8 % for the 3-symbol wide kernel (2 workgroups per CU: the late stage keeps a slot from its next item), 3-4 % for
-// 2 layers x 2 hops and for 2 hops x 2 symbols in the KPT = 4 tier; everything else is within 1 %.
+// Policy from interleaved same-box A/Bs of both placements over tools/perf_cases.py (profiles/round2_ta_placement_ab.txt;
+// resolution of the method ~2 %): late wins 1.5-3 % on the single-hop one-layer shapes, 3-6 % on narrow two-hop ones and
+// for 2-4 layers of one hop; early wins 5-10 % where only two workgroups fit a CU (3 symbols x CE_KPT REs in registers:
+// the late stage keeps a slot from its next item) and 4 % for 2 layers x 2 hops; the rest is within the resolution.
 constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
   if (CE_TA_LATE >= 0) return CE_TA_LATE != 0;
-  if (layers == 1) return nh == 2 && !(nd == 2 && kpt == 4);
-  return nh == 1;
+  if (nd > 0 && ce_min_waves(nh, nd, kpt, feat) == 2) return false;
+  if (layers >= 2 && nh == 2) return false;
+  return true;
 }
 #ifndef CE_PF1_LIMIT
 #define CE_PF1_LIMIT 4    // two hops: up to this many pilot REs x symbols per thread, hop 2's pilots are prefetched with hop 1's
@@ -778,6 +779,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
   // ------------------------------------------------------------ time alignment of one hop (S8)
   double tot_ta = 0.0;
   auto time_alignment = [&](int h) {
+    STAMP(9);
     const CeDevHop& lh = lp->hop[h];
     const float2* Ph = P + h * L * n_re_pad;
     // x[n] = P[k] at the pilot subcarriers of the LAST CDM group (for every layer, T:672-675), else 0;
@@ -842,9 +844,11 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
           for (int i = 0; i < 16; ++i) rowp[i] = v[i];
         }
         __syncthreads();
+        STAMP(14);
         if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0);
         if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1);
         __syncthreads();
+        STAMP(15);
       }
       // arg-max with first-index tie break on each side: key = (power bits, ~index)
       unsigned long long kh = 0ull, kt = 0ull;
@@ -1490,7 +1494,6 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estima
           }
         }
         __syncthreads();
-        if (c0 == 0) STAMP(9);
         if (tid < ACTIVE) {
           float4* o = out4 + (int64_t)c0 * ROW4 + tid;
 #pragma unroll 4

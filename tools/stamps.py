@@ -39,10 +39,13 @@ for name, case, interp in CASES:
         E.estimate_with_plan(plan, rx, pil, out)
         torch.cuda.synchronize()
         t = st.cpu().numpy().astype(np.float64) * 0.01   # us
-        t[:, 9] = np.where(t[:, 9] > 0, t[:, 9], t[:, 8])  # the direct writer has no staging stamp
+        ta0, ta1, ta2 = t[:, 9].copy(), t[:, 14].copy(), t[:, 15].copy()   # TA start (last hop), after the two radix-16 passes, after the bin sums
+        t[:, 9] = t[:, 8]
         d = np.diff(t[:, :12], axis=1)
         print(f"--- {name}: {n} items: median us per stage (item total {np.median(t[:,11]-t[:,0]):.1f} us, to end of writer {np.median(t[:,10]-t[:,0]):.1f}; kernel span {(t[:,11].max()-t[:,0].min()):.0f} us)")
         print("  ".join(f"{nm}={np.median(d[:, i]):.2f}" for i, nm in enumerate(names)), flush=True)
+        ta_end = np.where(t[:, 11] > ta2, np.where(t[:, 6] > ta2, np.minimum(t[:, 6], t[:, 11]), t[:, 11]), t[:, 6])
+        print(f"  time alignment (last hop): radix-16 passes {np.median(ta1 - ta0):.2f} us, bin sums {np.median(ta2 - ta1):.2f} us, arg-max + seconds {np.median(ta_end - ta2):.2f} us")
         print(f"  kernel entry -> first stage stamp (arguments, plan / twiddle / table copies to LDS, pilot loads issued): median {np.median(t[:, 0] - t[:, 13]):.2f} us, p95 {np.percentile(t[:, 0] - t[:, 13], 95):.2f} us")
         # residency: which CU each workgroup ran on (HW_ID bits 8-15: CU / SH / SE, XCC_ID), how many were resident
         # on a CU on average, and how long a CU waited between one workgroup's last stamp and the next one's first
