@@ -89,6 +89,8 @@ constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
   if (CE_TA_LATE >= 0) return CE_TA_LATE != 0;
   if (nd > 0 && ce_min_waves(nh, nd, kpt, feat) == 2) return false;
   if (layers >= 2 && nh == 2) return false;
+  // the widest shapes of the 4-workgroup tier (128 VGPRs) with the FIR compiled in: late placement would spill 1-4 registers
+  if (nh == 1 && nd * kpt == CE_MW4_LIMIT && (feat & CE_FEAT_FIR)) return false;
   return true;
 }
 #ifndef CE_PF1_LIMIT
