@@ -82,7 +82,7 @@ def ta_tie_alternatives(fx, item):
     return alts
 
 
-def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what="", ta_alternatives=()):
+def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what="", ta_alternatives=(), tol_rsrp=None):
     """Comparison protocol used everywhere: channel estimate error relative to the largest
     reference magnitude; scalars relative, except the residual noise whose floor is rounding
     noise of the EPRE (it is a difference of nearly equal quantities when nothing is smoothed);
@@ -93,7 +93,7 @@ def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what
     assert err <= tol_ch, f"{what}: ch_est rel-max err {err:.3e} > {tol_ch:.1e}"
     noise, rsrp, epre, ta, cfo = [float(x) for x in got_scalars]
     r_noise, r_rsrp, r_epre, r_ta, r_cfo = [float(x) for x in ref_scalars]
-    assert abs(rsrp - r_rsrp) <= tol_sc * abs(r_rsrp), f"{what}: rsrp {rsrp} vs {r_rsrp}"
+    assert abs(rsrp - r_rsrp) <= (tol_sc if tol_rsrp is None else tol_rsrp) * abs(r_rsrp), f"{what}: rsrp {rsrp} vs {r_rsrp}"
     assert abs(epre - r_epre) <= tol_sc * abs(r_epre), f"{what}: epre {epre} vs {r_epre}"
     assert abs(noise - r_noise) <= tol_sc * max(abs(r_noise), 1e-2 * abs(r_epre)), f"{what}: noise {noise} vs {r_noise}"
     assert ta == r_ta or ta in ta_alternatives, f"{what}: time alignment {ta!r} vs {r_ta!r}"      # index work: bit-exact (T:698)
