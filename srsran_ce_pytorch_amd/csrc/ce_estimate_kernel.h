@@ -42,6 +42,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_MIN_WAVES_LIGHT
 #define CE_MIN_WAVES_LIGHT 3   // the same for single-hop register-path kernels built without the FIR ("none" / "mean" smoothing)
 #endif
+#ifndef CE_MIN_WAVES_L2H2
+#define CE_MIN_WAVES_L2H2 3   // re-read path, 2-4 layers x 2 hops (3: 4-11 spilled VGPRs; 2: none, but one workgroup less per CU on narrow bands)
+#endif
 #ifndef CE_MW5_LIMIT
 #define CE_MW5_LIMIT 0   // single hop: up to this many pilot REs x symbols per thread, 5 workgroups per CU (<= 96 VGPRs)
 #endif
@@ -66,9 +69,9 @@ constexpr int CE_FEAT_FIR = 1, CE_FEAT_EXT = 2;
 // the allocator must leave room for, and whether the DM-RS symbols stay in registers next to the received pilots
 // (otherwise the three stages that use them re-read them through L2).  The 3-symbol wide kernel measured 2.93 ms at
 // 2 workgroups per CU with everything in registers vs 3.23 ms at 3 with the symbols re-read (3.6 ms generic path).
-constexpr int ce_min_waves(int nh, int nd, int kpt, int feat) {
+constexpr int ce_min_waves(int nh, int nd, int kpt, int feat, int layers = 1) {
   const int n = nd * kpt;
-  if (nd == 0) return CE_MIN_WAVES;
+  if (nd == 0) return (layers >= 2 && nh == 2) ? CE_MIN_WAVES_L2H2 : CE_MIN_WAVES;
   if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= 14 ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
   return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
 }
@@ -596,7 +599,7 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
 // allocations are latency-bound, so residency is what they are short of.
 // FEAT = the smoothing / in-painting code compiled in (CE_FEAT_*).
 template <int L, int NH, int ND, int KPT, int FEAT>
-__global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT)) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
+__global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_estimate_kernel(const CeDevPlan* __restrict__ plan,
                                                          const uint16_t* __restrict__ re_idx,
                                                          const uint16_t* __restrict__ ta_inv,
                                                          const float2* __restrict__ tw, CeKernelArgs a) {

@@ -18,6 +18,7 @@ CASES = [
     ("L1 2 hops x 2dmrs 80 PRB in 273", CS("h2m", 273, [H([1, 5], 0, 80, 0, 7), H([8, 12], 150, 80, 7, 7)]), "linear"),
     ("L2 2 hops x 2dmrs 136 PRB", CS("h2l2", 273, [H([1, 5], 0, 136, 0, 7), H([8, 12], 137, 136, 7, 7)], n_layers=2), "linear"),
     ("L4 2 hops x 2dmrs 136 PRB", CS("h2l4", 273, [H([1, 5], 0, 136, 0, 7, BOTH), H([8, 12], 137, 136, 7, 7, BOTH)], n_layers=4), "linear"),
+    ("L2 2 hops x 2dmrs 12 PRB in 52", CS("h2l2n", 52, [H([1, 5], 3, 12, 0, 7), H([8, 12], 30, 12, 7, 7)], n_layers=2), "linear"),
     ("L1 type-2 mask filter", CS("t2", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "linear"),
     ("L1 cnn in-painting", S.bench_case("filter", 1), "cnn"),
     ("L1 cnn type-2 mask", CS("t2c", 273, [H([2, 11], 0, 273, re_masks=[S.TYPE2_CDM0])]), "cnn"),
