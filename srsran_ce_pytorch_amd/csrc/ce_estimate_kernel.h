@@ -46,7 +46,8 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #define CE_MIN_WAVES_L2H2 3   // re-read path, 2-4 layers x 2 hops (3: 4-11 spilled VGPRs; 2: none, but one workgroup less per CU on narrow bands)
 #endif
 #ifndef CE_MW5_LIMIT
-#define CE_MW5_LIMIT 0   // single hop: up to this many pilot REs x symbols per thread, 5 workgroups per CU (<= 96 VGPRs)
+#define CE_MW5_LIMIT 2   // single hop: up to this many pilot REs x symbols per thread, 5 workgroups per CU (<= 96 VGPRs: the FIR shapes spill 1-2
+                         // registers for it and gain 10-14 % on <= 25-PRB hops; at 4 per thread the 6-8 spilled registers cost more than the fifth workgroup gives)
 #endif
 #ifndef CE_MW4_LIMIT
 #define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
@@ -436,13 +437,18 @@ __device__ __forceinline__ void cnn_inpaint_layer(float2* dst, float2* pong, uns
 // fully unrolled window over P (one LDS read per input sample, taps held in registers).  Last wave: fits the
 // virtual pilots (two 16-lane groups), then its first 2*PAD lanes compute the outputs whose window reaches
 // past a band edge.  One barrier separates all reads of P from the writes.
-template <int PAD>
+// CV = consecutive outputs per FIR thread: CE_CONV_C (9) covers the widest bands with the 192 FIR threads; the narrow tiers
+// take just enough for their band (ce_conv_c) -- fewer float64 accumulators (4 VGPRs per output: the 128 -> 96 VGPR step
+// that lets a fifth workgroup onto a CU) and a shorter serial window.  Each output adds its taps in the same order
+// whatever CV is: results are bit-identical.
+constexpr int ce_conv_c(int nd, int kpt) { return nd == 0 ? CE_CONV_C : kpt == 1 ? 2 : kpt == 2 ? 3 : kpt == 4 ? 6 : CE_CONV_C; }
+template <int PAD, int CV>
 __device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils, int pad_rt, const double* rcz,
                                                 float2* vpb, int tid, double vmx, double vin, double vid) {
-  constexpr int CV = CE_CONV_C, NCV = NT - 64, NTAP = 2 * PAD + 1;
-  static_assert(CV == 9, "the ordering asm below names the nine accumulators");
-  // rc_ext[j], j = 0..NTAP-1: the actual taps centred in the PAD-wide template (zeros outside)
-  const double* rc = rcz + (CV - 1) - (PAD - pad_rt);
+  constexpr int NCV = NT - 64, NTAP = 2 * PAD + 1;
+  // rc_ext[j], j = 0..NTAP-1: the actual taps centred in the PAD-wide template (zeros outside); the host lays the taps
+  // out behind CE_CONV_C - 1 zeros (ce_plan.h: rcz)
+  const double* rc = rcz + (CE_CONV_C - 1) - (PAD - pad_rt);
   const int m0 = tid * CV;
   double ar[CV], ai[CV];      // defined on the FIR threads only (not live across the virtual-pilot branch)
   double er = 0.0, ei = 0.0;  // edge output of this lane (last wave)
@@ -494,8 +500,8 @@ __device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils
       // accumulators pass through the same statement).  Left alone, the optimizer hoists all CV+2*PAD reads and
       // their float64 conversions (4 VGPRs a sample, 92 in all) above the first MAC.
       if ((w & 1) == 0) {
-        asm volatile("" : "+v"(idx), "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]), "+v"(ar[7]), "+v"(ar[8]));
-        asm volatile("" : "+v"(idx), "+v"(ai[0]), "+v"(ai[1]), "+v"(ai[2]), "+v"(ai[3]), "+v"(ai[4]), "+v"(ai[5]), "+v"(ai[6]), "+v"(ai[7]), "+v"(ai[8]));
+#pragma unroll
+        for (int o = 0; o < CV; ++o) asm volatile("" : "+v"(idx), "+v"(ar[o]), "+v"(ai[o]));
       }
       const float2 x = Pl[idx];
       const double dx = (double)x.x, dy = (double)x.y;
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
 #pragma unroll 1
         for (int l = 0; l < L; ++l) {
           float2* Pl = Ph + l * n_re_pad;
-          smooth_windowed<7>(Pl, n_re, n_pils, pad, rcz, vpb, tid, vmx, vin, vid);  // 15 taps: >= 3 PRB, comb 2
+          smooth_windowed<7, ce_conv_c(ND, KPT)>(Pl, n_re, n_pils, pad, rcz, vpb, tid, vmx, vin, vid);  // 15 taps: >= 3 PRB, comb 2
         }
       } else {
         // generic form (very wide bands): copy [virtual ; P ; virtual] to the scratch, one output per thread
