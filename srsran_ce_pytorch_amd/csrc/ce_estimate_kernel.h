@@ -45,6 +45,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_MIN_WAVES_L2H2
 #define CE_MIN_WAVES_L2H2 3   // re-read path, 2-4 layers x 2 hops (3: 4-11 spilled VGPRs; 2: none, but one workgroup less per CU on narrow bands)
 #endif
+#ifndef CE_MW3_LIMIT
+#define CE_MW3_LIMIT 14  // single hop: up to this many pilot REs x symbols per thread, 3 workgroups per CU (168 VGPRs)
+#endif
 #ifndef CE_MW5_LIMIT
 #define CE_MW5_LIMIT 2   // single hop: up to this many pilot REs x symbols per thread, 5 workgroups per CU (<= 96 VGPRs: the FIR shapes spill 1-2
                          // registers for it and gain 10-14 % on <= 25-PRB hops; at 4 per thread the 6-8 spilled registers cost more than the fifth workgroup gives)
@@ -73,7 +76,7 @@ constexpr int CE_FEAT_FIR = 1, CE_FEAT_EXT = 2;
 constexpr int ce_min_waves(int nh, int nd, int kpt, int feat, int layers = 1) {
   const int n = nd * kpt;
   if (nd == 0) return (layers >= 2 && nh == 2) ? CE_MIN_WAVES_L2H2 : CE_MIN_WAVES;
-  if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= 14 ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
+  if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= CE_MW3_LIMIT ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
   return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
 }
 constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {

@@ -27,6 +27,7 @@ CASES = [
     ("L1 66 PRB in 106", CS("mid", 106, [H([2, 11], 20, 66)]), "linear"),
     ("L1 6 PRB in 52", CS("tiny", 52, [H([2, 11], 10, 6)]), "linear"),
     ("L1 4dmrs 20 PRB in 52", CS("d4n", 52, [H([2, 5, 8, 11], 7, 20)]), "linear"),
+    ("L1 4dmrs 150 PRB in 273", CS("d4w", 273, [H([2, 5, 8, 11], 60, 150)]), "linear"),
     ("L1 3dmrs 150 PRB in 273", CS("d3w", 273, [H([2, 7, 11], 60, 150)]), "linear"),
     ("L1 2dmrs 160 PRB in 273", CS("d2w", 273, [H([2, 11], 60, 160)]), "linear"),
     ("L1 3dmrs 70 PRB in 106", CS("d3m", 106, [H([2, 7, 11], 30, 70)]), "linear"),
