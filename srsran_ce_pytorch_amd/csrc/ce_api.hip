@@ -428,15 +428,29 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       for (int h = 0; h < d->n_hops; ++h) n_max = P.hop[h].n_sc_hop > n_max ? P.hop[h].n_sc_hop : n_max;
       P.cnn_n_max = n_max;
       P.cnn_h_stride = (n_max + 1) & ~1;
-      const int aux = ((n_max + 1) & ~1) * 8 + 2 * ((n_max + 15) & ~15);
+      const int aux = ((n_max + 1) & ~1) * 8;
       int rows = P.n_hops * L;
       const int fixed = ce_lds_layout(P.n_hops, L, (n_re + 1) & ~1, 0).total;
       if (fixed + rows * P.cnn_h_stride * 8 + aux > 160 * 1024 - 256) { rows = 1; P.cnn_rowwise = 1; }
       const int h_bytes = rows * P.cnn_h_stride * 8;
       P.cnn_pong_off = h_bytes;
-      P.cnn_m_off = h_bytes + ((n_max + 1) & ~1) * 8;
-      const int cnn_need = P.cnn_m_off + 2 * ((n_max + 15) & ~15);
+      const int cnn_need = h_bytes + aux;
       if (cnn_need > P.scratch_bytes) P.scratch_bytes = cnn_need;
+      // longest run of unknown REs between pilots, across a PRB boundary or at a band edge: the in-painting iterates one
+      // run per thread in registers (ce_estimate_kernel.h: cnn_inpaint_runs)
+      int gmax = 0;
+      for (int h = 0; h < d->n_hops; ++h)
+        for (int c = 0; c < n_cdm; ++c) {
+          const unsigned m12 = (P.hop[h].mask12 >> (16 * c)) & 0xFFFu;
+          int first = 0, last = 11, run = 0;
+          while (!((m12 >> first) & 1u)) ++first;
+          while (!((m12 >> last) & 1u)) --last;
+          for (int r = first; r <= last; ++r) {
+            if ((m12 >> r) & 1u) run = 0; else if (++run > gmax) gmax = run;
+          }
+          if ((11 - last) + first > gmax) gmax = (11 - last) + first;
+        }
+      P.cnn_gmax = gmax;
     }
     if (d->interp == CE_INTERP_CNN) {
       double a = d->cnn_smoothing_alpha;

@@ -378,60 +378,119 @@ __device__ __forceinline__ float2 lp3x2(const float2* x, int i, int n) {
   return make_float2((float)((0.25 * r[0] + 0.5 * r[1]) + 0.25 * r[2]), (float)((0.25 * q[0] + 0.5 * q[1]) + 0.25 * q[2]));
 }
 
-// Partial-convolution in-painting of one layer over a hop band of n subcarriers (C:473-508, C:276-295).
-// x lives in LDS (ping-pong between `dst` and `pong`), the fill mask m in two byte arrays.  The loop stops
-// early at a bitwise fixed point (x and m unchanged), after which every further reference iteration is the
-// identity -- the comb-2 DM-RS reaches it after two iterations instead of max(6, n/8).  num/(den+eps) is
-// evaluated as num * (1/(den+eps)) with the five possible reciprocals tabulated (<= 1 ulp in float64
-// before the float32 round trip).  Result ends in `dst`.
-__device__ __forceinline__ void cnn_inpaint_layer(float2* dst, float2* pong, unsigned char* m_a, unsigned char* m_b, const float2* Pl,
-                                  int n, unsigned mask12, int dpp, int n_iters, const double* rcp, int tid) {
+// One run of g <= G unknown REs between two pilots (or between a band edge and a pilot), iterated in registers exactly as
+// the reference iterates the whole band (C:489-505): x <- (0.25 x[i-1] + 0.5 x[i] + 0.25 x[i+1]) / (den + eps) in float64
+// with a float32 round trip per iteration, den = the partial-convolution mask sum, the mask growing by one RE per side and
+// iteration.  `kind`: 0 = pilots Lv / Rv on both sides; 1 = the run starts at subcarrier 0 (reflect padding: index -1 is
+// index +1, i.e. the left neighbour of element 0 is its right neighbour); 2 = the run ends at the band's last subcarrier
+// (index n is index n-2: the right neighbour of the last element is its left neighbour).  Stops early at the run's own
+// bitwise fixed point.  num / (den + eps) is evaluated as num * rcp[code], rcp = the five possible reciprocals (<= 1 ulp in
+// float64 before the float32 round trip).
+template <int G>
+__device__ __forceinline__ void cnn_inpaint_run(float2 (&x)[G], int g, float2 Lv, float2 Rv, int kind, int n_iters, const double* rcp) {
+  unsigned m = 0u;  // bit i: mask of element i (unknown REs start at 0; the bounding pilots count as 1)
+#pragma unroll 1
+  for (int it = 0; it < n_iters; ++it) {
+    float2 xn[G];
+    unsigned mn = m;
+    bool changed = false;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      xn[i] = x[i];
+      if (i < g) {
+        float2 a = Lv, c = Rv;
+        int ma = 1, mc = 1;
+        if (i > 0) {
+          a = x[i > 0 ? i - 1 : 0];
+          ma = (int)((m >> (i > 0 ? i - 1 : 0)) & 1u);
+        }
+        if (i < g - 1) {
+          c = x[i + 1 < G ? i + 1 : G - 1];
+          mc = (int)((m >> (i + 1)) & 1u);
+        }
+        if (kind == 1 && i == 0) { a = c; ma = mc; }
+        if (kind == 2 && i == g - 1) { c = a; mc = ma; }
+        const float2 b = x[i];
+        const int mb = (int)((m >> i) & 1u), code = ma + 2 * mb + mc;
+        const double w = rcp[code];
+        xn[i] = make_float2((float)(((0.25 * (double)a.x + 0.5 * (double)b.x) + 0.25 * (double)c.x) * w),
+                            (float)(((0.25 * (double)a.y + 0.5 * (double)b.y) + 0.25 * (double)c.y) * w));
+        if (code > 0) mn |= 1u << i;
+        changed |= (__float_as_uint(xn[i].x) != __float_as_uint(b.x)) | (__float_as_uint(xn[i].y) != __float_as_uint(b.y));
+      }
+    }
+    changed |= mn != m;
+#pragma unroll
+    for (int i = 0; i < G; ++i) x[i] = xn[i];
+    m = mn;
+    if (!changed) break;
+  }
+}
+
+// All runs of unknown REs of one layer over a hop band of n subcarriers, one run per thread and turn: between two pilots
+// the iteration never looks past them (pilots keep their value and their mask), and at the band edges the reflect padding
+// folds back into the run itself, so the runs are independent and need neither LDS traffic nor barriers between
+// iterations (150 barrier-separated LDS sweeps for a 100-PRB type-2 hop before).  `x` = the band with the pilots in place.
+template <int G>
+__device__ __forceinline__ void cnn_inpaint_runs(float2* x, int n, unsigned mask12, int dpp, int n_iters, const double* rcp, int tid) {
+  const unsigned mask24 = mask12 | (mask12 << 12);
+  // a run starts after pilot RE r when RE r+1 (of this or the next PRB) is not a pilot
+  const unsigned gapmask = mask12 & ~(mask24 >> 1) & 0xFFFu;
+  const int nne = __popc(gapmask), n_prbs = n / 12, first = __ffs(mask12) - 1;
+  const int total = n_prbs * nne + (first > 0 ? 1 : 0);
+  for (int w = tid; w < total; w += NT) {
+    float2 v[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] = make_float2(0.f, 0.f);
+    int start, g, kind = 0;
+    float2 Lv = make_float2(0.f, 0.f), Rv = Lv;
+    if (w == n_prbs * nne) {  // the run in front of the first pilot
+      start = 0; g = first; kind = 1;
+      Rv = x[first];
+    } else {
+      const int q = w / nne, jj = w - q * nne;
+      unsigned mm = gapmask;
+      for (int c = 0; c < jj; ++c) mm &= mm - 1u;
+      const int r = __ffs(mm) - 1;                       // the jj-th pilot of the PRB that is followed by a run
+      const int a = 12 * q + r;
+      g = __ffs(mask24 >> (r + 1)) - 1;                  // distance to the next pilot (possibly in the next PRB)
+      start = a + 1;
+      Lv = x[a];
+      if (start + g >= n) { g = n - start; kind = 2; }   // the last PRB's wrap-around run ends at the band edge
+      else Rv = x[start + g];
+    }
+    if (g <= 0) continue;
+    cnn_inpaint_run<G>(v, g, Lv, Rv, kind, n_iters, rcp);
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+      if (i < g) x[start + i] = v[i];
+  }
+}
+
+// Partial-convolution in-painting of one layer over a hop band of n subcarriers (C:473-508, C:276-295), then the two
+// low-pass passes with the pilots restored (C:507-508).  Result ends in `dst`; `pong` is a second band-sized buffer.
+// `gmax` = the longest run of unknown REs (plan: cnn_gmax).
+__device__ __forceinline__ void cnn_inpaint_layer(float2* dst, float2* pong, const float2* Pl, int n, unsigned mask12, int dpp,
+                                                  int n_iters, int gmax, const double* rcp, int tid) {
   for (int i = tid; i < n; i += NT) {
     const int q = i / 12, r = i - 12 * q;
     const bool known = (mask12 >> r) & 1u;
     dst[i] = known ? Pl[q * dpp + __popc(mask12 & ((1u << r) - 1u))] : make_float2(0.f, 0.f);
-    m_a[i] = known ? 1 : 0;
   }
   __syncthreads();
-  float2 *cur = dst, *nxt = pong;
   if (dpp < 12) {  // known_mask.all() skips the in-painting (C:487-488)
-    unsigned char *mc = m_a, *mn = m_b;
-#pragma unroll 1
-    for (int it = 0; it < n_iters; ++it) {
-      int changed = 0;
-      for (int i = tid; i < n; i += NT) {
-        const int il = reflect_idx(i - 1, n), ir = reflect_idx(i + 1, n);
-        const float2 b = cur[i];
-        const int mb = mc[i], code = mc[il] + 2 * mb + mc[ir];
-        const int q = i / 12, r = i - 12 * q;
-        float2 xn = b;
-        if (!((mask12 >> r) & 1u)) {
-          const float2 a = cur[il], c = cur[ir];
-          const double w = rcp[code];
-          xn = make_float2((float)(((0.25 * (double)a.x + 0.5 * (double)b.x) + 0.25 * (double)c.x) * w),
-                           (float)(((0.25 * (double)a.y + 0.5 * (double)b.y) + 0.25 * (double)c.y) * w));
-        }
-        const int mnew = mb | (code > 0);
-        changed |= (__float_as_uint(xn.x) != __float_as_uint(b.x)) | (__float_as_uint(xn.y) != __float_as_uint(b.y)) | (mnew != mb);
-        nxt[i] = xn;
-        mn[i] = (unsigned char)mnew;
-      }
-      const int any = __syncthreads_or(changed);
-      float2* t = cur; cur = nxt; nxt = t;
-      unsigned char* u = mc; mc = mn; mn = u;
-      if (!any) break;
-    }
+    if (gmax <= 4) cnn_inpaint_runs<4>(dst, n, mask12, dpp, n_iters, rcp, tid);
+    else cnn_inpaint_runs<11>(dst, n, mask12, dpp, n_iters, rcp, tid);
+    __syncthreads();
   }
   // low-pass twice; known pilots are restored unless every RE is a pilot (C:487-488, C:507-508)
   for (int i = tid; i < n; i += NT) {
     const int q = i / 12, r = i - 12 * q;
-    nxt[i] = (dpp < 12 && ((mask12 >> r) & 1u)) ? cur[i] : lp3x2(cur, i, n);
+    pong[i] = (dpp < 12 && ((mask12 >> r) & 1u)) ? dst[i] : lp3x2(dst, i, n);
   }
   __syncthreads();
-  if (nxt != dst) {
-    for (int i = tid; i < n; i += NT) dst[i] = nxt[i];
-    __syncthreads();
-  }
+  for (int i = tid; i < n; i += NT) dst[i] = pong[i];
+  __syncthreads();
 }
 
 // RC FIR over one layer's pilots, in place: conv([virtual head ; P ; virtual tail], rc, "same") cropped back
@@ -1402,8 +1461,6 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   if constexpr ((FEAT & CE_FEAT_EXT) != 0) {
     if (cnn_iterated) {
       float2* pong = reinterpret_cast<float2*>(reinterpret_cast<unsigned char*>(scratch) + lp->cnn_pong_off);
-      unsigned char* m_a = reinterpret_cast<unsigned char*>(scratch) + lp->cnn_m_off;
-      unsigned char* m_b = m_a + ((lp->cnn_n_max + 15) & ~15);
       auto owner = [&](int sc, int sym) __attribute__((always_inline)) -> int {
         for (int h = NH - 1; h >= 0; --h) {
           const CeDevHop& lh = lp->hop[h];
@@ -1425,7 +1482,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         const unsigned mask12 = (unsigned)((lh.mask12 >> (16 * c)) & 0xFFFu);
         const int n_it = lh.n_sc_hop / 8 > 6 ? lh.n_sc_hop / 8 : 6;  // C:293
         float2* rowp = scratch + (rowwise ? 0 : hl * lp->cnn_h_stride);
-        cnn_inpaint_layer(rowp, pong, m_a, m_b, P + (h * L + l) * n_re_pad, lh.n_sc_hop, mask12, lh.dpp[c], n_it, lp->cnn_rcp, tid);
+        cnn_inpaint_layer(rowp, pong, P + (h * L + l) * n_re_pad, lh.n_sc_hop, mask12, lh.dpp[c], n_it, lp->cnn_gmax, lp->cnn_rcp, tid);
         if (rowwise) {
           const int ns = lh.sym1 - lh.sym0, cnt = lh.n_sc_hop * ns;
           for (int i = tid; i < cnt; i += NT) {
