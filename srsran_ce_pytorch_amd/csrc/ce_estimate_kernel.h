@@ -34,7 +34,7 @@ constexpr int NW = NT / 64;
 constexpr double kInvPi = 0.31830988618379067153776752674503;
 
 #ifndef CE_ABLATE
-#define CE_ABLATE 0   // timing experiments only (tools/ablate.py): 1 TA, 2 smoothing, 4 residual, 8 writer, 16 CFO, 32 input loads
+#define CE_ABLATE 0   // timing experiments only (tools/ablate.py): 1 TA, 2 smoothing, 4 residual, 8 writer, 16 CFO, 32 input loads, 64 writer without LDS reads
 #endif
 #ifndef CE_MIN_WAVES
 #define CE_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for (3 workgroups per CU; 4 would spill)
@@ -646,7 +646,7 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
           if (q[e] == nprb[e] - 1 && tail_r[e]) lo = hi = n_re - 1;  // at/after the last pilot: hold (T:316,321)
           lo = lo < 0 ? 0 : lo;                                       // at/before the first pilot: hold (T:315,320)
           if (!valid) lo = hi = 0;
-          const float2 u = Pe[e][lo], v = Pe[e][hi];
+          const float2 u = (CE_ABLATE & 64) ? make_float2(1.f, 2.f) : Pe[e][lo], v = (CE_ABLATE & 64) ? u : Pe[e][hi];  // 64: timing experiment, no LDS reads in the writer
           y[e] = valid ? make_float2(u.x + al[e] * (v.x - u.x), u.y + al[e] * (v.y - u.y)) : make_float2(0.f, 0.f);
           q[e] += QS;
           ro[e] += dro[e];
@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       r = make_float2(cs, sn);
     }
     rot_final[tid] = r;
-    if (tid == 0) {
+    if (tid == 0 && !(CE_ABLATE & 128)) {  // 128: timing experiment, no scalar outputs
       const double np = lp->inv_n_pilots;
       a.rsrp[item] = tot_rsrp * np * lp->inv_layers;
       a.epre[item] = tot_epre * np;
@@ -1637,7 +1637,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       time_alignment(h);
     }
   }
-  if (tid == 0) a.ta[item] = (NH == 2) ? tot_ta / 2.0 : tot_ta;  // T:918-919
+  if (tid == 0 && !(CE_ABLATE & 128)) a.ta[item] = (NH == 2) ? tot_ta / 2.0 : tot_ta;  // T:918-919
   STAMP(11);
 }
 

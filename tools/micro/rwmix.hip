@@ -47,6 +47,63 @@ __global__ __launch_bounds__(256) void rwmix(const float2* __restrict__ rx, cons
   }
 }
 
+// The estimator's start-up, grafted onto the pattern above, to see which part of it (if any) explains the few per cent the
+// estimator's kernel sits above `rwmix<true, true>`:  PRE = every workgroup first copies 4.4 KB of per-launch tables
+// (plan + twiddles: the same addresses for all workgroups) into LDS and reads a few scalars through a pointer;
+// EAGER = the item's 28 pilot loads per thread are requested back to back (unrolled, clamped index) instead of in a loop.
+struct SkelPlan { int n_re, n_sc, a, b, c, d, e, f; };
+template <bool PRE, bool EAGER>
+__global__ __launch_bounds__(256) void skel(const float2* __restrict__ rx, const float2* __restrict__ pil, float4* __restrict__ out,
+                                            int n_ports, const float4* __restrict__ tab, const SkelPlan* __restrict__ plan) {
+  extern __shared__ float red[];
+  const int tid = threadIdx.x;
+  int item = blockIdx.x;
+  {
+    const int per = 8 * n_ports, g = item / per, j = item - g * per;
+    item = (g * 8 + (j & 7)) * n_ports + (j >> 3);
+  }
+  const int slot = item / n_ports;
+  const float2* r = rx + (size_t)item * N_SC * N_SYM;
+  float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+  int n_re = N_RE;
+  if (PRE) {
+    if (tid < 276) tv = tab[tid];
+    n_re = plan->n_re + (plan->e & 0);
+  }
+  float acc = 0.f;
+  if (EAGER) {
+    float2 a[7], b[7], p[7], q[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int k = tid + i * 256, kk = k < n_re ? k : 0;
+      a[i] = r[2 * N_SC + 2 * kk]; b[i] = r[11 * N_SC + 2 * kk];
+      p[i] = pil[(size_t)slot * N_RE * 2 + kk]; q[i] = pil[(size_t)slot * N_RE * 2 + N_RE + kk];
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (tid + i * 256 < n_re) acc += a[i].x * p[i].x + a[i].y * p[i].y + b[i].x * q[i].x + b[i].y * q[i].y;
+  } else {
+    for (int k = tid; k < n_re; k += 256) {
+      const float2 a = r[2 * N_SC + 2 * k], b = r[11 * N_SC + 2 * k];
+      const float2 p = pil[(size_t)slot * N_RE * 2 + k], q = pil[(size_t)slot * N_RE * 2 + N_RE + k];
+      acc += a.x * p.x + a.y * p.y + b.x * q.x + b.y * q.y;
+    }
+  }
+  float* lds_tab = red + 256;
+  if (PRE && tid < 276) reinterpret_cast<float4*>(lds_tab)[tid] = tv;
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  float v = red[0];
+  if (PRE) v += lds_tab[(tid * 7) & 1023] * 1e-30f;
+  if (tid < ACTIVE) {
+    float4* o = out + (size_t)item * (N_SC * ROW4) + tid;
+    const float4 val = make_float4(v, v + 1.f, v + 2.f, (float)item);
+#pragma unroll 4
+    for (int s = tid / ROW4; s < N_SC; s += ACTIVE / ROW4) { *o = val; o += ACTIVE; }
+  }
+}
+
 // Upper bound of a "sweep writer" redesign: persistent workgroups; each alternates between reading + reducing one item's
 // pilots and writing one item's worth of output in 4 KB chunks handed out by a global ticket counter, so that the chip's
 // stores advance through the output in address order while the reads stay interleaved as in the fused kernel.  (A real
@@ -188,6 +245,26 @@ int main() {
     }
     double t = time_ms([&] { rwmix<false, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, 1); }, 5);
     printf("%d WG/CU write only                           : %.3f ms  %.0f GB/s of stores\n", wgs, t, (double)n_items * 366912 / t / 1e6);
+  }
+  {
+    float4* tab; SkelPlan* plan; SkelPlan hp = {N_RE, N_SC, 0, 0, 0, 0, 0, 0};
+    CHECK(hipMalloc(&tab, 276 * 16)); CHECK(hipMemset(tab, 0, 276 * 16));
+    CHECK(hipMalloc(&plan, sizeof(SkelPlan))); CHECK(hipMemcpy(plan, &hp, sizeof(hp), hipMemcpyHostToDevice));
+    const int lds = 50 * 1024;
+    CHECK(hipFuncSetAttribute((const void*)skel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipFuncSetAttribute((const void*)skel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipFuncSetAttribute((const void*)skel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipFuncSetAttribute((const void*)skel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    for (int rep = 0; rep < 2; ++rep) {
+      double t = time_ms([&] { skel<false, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, tab, plan); }, 5);
+      printf("skeleton 3 WG/CU: loop loads, no table copy    : %.3f ms  %.0f GB/s algorithmic\n", t, alg / t / 1e6);
+      t = time_ms([&] { skel<true, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, tab, plan); }, 5);
+      printf("skeleton 3 WG/CU: loop loads, 4.4 KB table copy: %.3f ms  %.0f GB/s algorithmic\n", t, alg / t / 1e6);
+      t = time_ms([&] { skel<false, true><<<n_items, 256, lds>>>(rx, pil, out, n_ports, tab, plan); }, 5);
+      printf("skeleton 3 WG/CU: eager loads, no table copy   : %.3f ms  %.0f GB/s algorithmic\n", t, alg / t / 1e6);
+      t = time_ms([&] { skel<true, true><<<n_items, 256, lds>>>(rx, pil, out, n_ports, tab, plan); }, 5);
+      printf("skeleton 3 WG/CU: eager loads, table copy      : %.3f ms  %.0f GB/s algorithmic\n", t, alg / t / 1e6);
+    }
   }
   unsigned* bar; CHECK(hipMalloc(&bar, 4));
   for (int wgs : {1, 2, 3}) {
