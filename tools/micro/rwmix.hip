@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void rwmix(const float2* __restrict__ rx, cons
 // (plan + twiddles: the same addresses for all workgroups) into LDS and reads a few scalars through a pointer;
 // EAGER = the item's 28 pilot loads per thread are requested back to back (unrolled, clamped index) instead of in a loop.
 struct SkelPlan { int n_re, n_sc, a, b, c, d, e, f; };
-template <bool PRE, bool EAGER>
+template <bool PRE, bool EAGER, int REGS = 0>
 __global__ __launch_bounds__(256) void skel(const float2* __restrict__ rx, const float2* __restrict__ pil, float4* __restrict__ out,
                                             int n_ports, const float4* __restrict__ tab, const SkelPlan* __restrict__ plan) {
   extern __shared__ float red[];
@@ -64,6 +64,9 @@ __global__ __launch_bounds__(256) void skel(const float2* __restrict__ rx, const
   }
   const int slot = item / n_ports;
   const float2* r = rx + (size_t)item * N_SC * N_SYM;
+  float live[REGS > 0 ? REGS : 1];  // REGS > 0: that many VGPRs stay live from the first to the last instruction (footprint experiment)
+#pragma unroll
+  for (int i = 0; i < REGS; ++i) { live[i] = (float)(tid + i); asm volatile("" : "+v"(live[i])); }
   float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
   int n_re = N_RE;
   if (PRE) {
@@ -102,6 +105,8 @@ __global__ __launch_bounds__(256) void skel(const float2* __restrict__ rx, const
 #pragma unroll 4
     for (int s = tid / ROW4; s < N_SC; s += ACTIVE / ROW4) { *o = val; o += ACTIVE; }
   }
+#pragma unroll
+  for (int i = 0; i < REGS; ++i) asm volatile("" : : "v"(live[i]));
 }
 
 // Upper bound of a "sweep writer" redesign: persistent workgroups; each alternates between reading + reducing one item's
@@ -255,8 +260,11 @@ int main() {
     CHECK(hipFuncSetAttribute((const void*)skel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CHECK(hipFuncSetAttribute((const void*)skel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CHECK(hipFuncSetAttribute((const void*)skel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipFuncSetAttribute((const void*)skel<true, true, 130>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     for (int rep = 0; rep < 2; ++rep) {
-      double t = time_ms([&] { skel<false, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, tab, plan); }, 5);
+      double t = time_ms([&] { skel<true, true, 130><<<n_items, 256, lds>>>(rx, pil, out, n_ports, tab, plan); }, 5);
+      printf("skeleton 3 WG/CU: eager loads, table copy, +130 live VGPRs: %.3f ms  %.0f GB/s algorithmic\n", t, alg / t / 1e6);
+      t = time_ms([&] { skel<false, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, tab, plan); }, 5);
       printf("skeleton 3 WG/CU: loop loads, no table copy    : %.3f ms  %.0f GB/s algorithmic\n", t, alg / t / 1e6);
       t = time_ms([&] { skel<true, false><<<n_items, 256, lds>>>(rx, pil, out, n_ports, tab, plan); }, 5);
       printf("skeleton 3 WG/CU: loop loads, 4.4 KB table copy: %.3f ms  %.0f GB/s algorithmic\n", t, alg / t / 1e6);
