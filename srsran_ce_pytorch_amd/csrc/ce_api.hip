@@ -482,6 +482,18 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (d->smoothing == CE_SMOOTH_MMSE || (d->interp == CE_INTERP_CNN && !P.cnn_comb2)) P.feat = 3;
   if (P.feat == 3 && P.reg_nd > 0 && !ce_reg_has_ext(P.n_hops, P.reg_nd, P.reg_kpt)) P.reg_nd = 0;
 
+  // Two layers' TA transforms side by side (threads 128-255 are idle in the radix-16 passes when <= 8 residues carry pilots)
+  // where the second set of residue blocks fits the LDS share the multi-layer kernels' three workgroups per CU leave free
+  P.ta_lp = 1;
+  if (L >= 2 && !getenv("CE_TA_LP1")) {  // env: A/B knob
+    int nres_max = 0;
+    for (int h = 0; h < d->n_hops; ++h) nres_max = std::max(nres_max, (int)P.hop[h].ta_nres);
+    const int sb2 = std::max(P.scratch_bytes, 2 * 8 * CE_TA_ROW * 8);
+    if (nres_max <= 8 && ce_lds_layout(P.n_hops, L, P.n_re_pad, sb2).total <= 53 * 1024) {
+      P.ta_lp = 2;
+      P.scratch_bytes = sb2;
+    }
+  }
   CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
   if (const char* pad = getenv("CE_LDS_PAD_BYTES")) lay.total += atoi(pad) & ~15;  // tuning knob: lowers the workgroups resident per CU
   if (lay.total > 160 * 1024) { delete p; return fail(CE_ERR_UNSUPPORTED, "plan needs %d B of LDS (> 160 KiB)", lay.total); }

@@ -504,19 +504,27 @@ __device__ __forceinline__ void cnn_inpaint_layer(float2* dst, float2* pong, con
 // that lets a fifth workgroup onto a CU) and a shorter serial window.  Each output adds its taps in the same order
 // whatever CV is: results are bit-identical.
 constexpr int ce_conv_c(int nd, int kpt) { return nd == 0 ? CE_CONV_C : kpt == 1 ? 2 : kpt == 2 ? 3 : kpt == 4 ? 6 : CE_CONV_C; }
+// `nl` = 1 or 2 layers in one call (rows `ls` elements apart): with two, FIR threads 0-95 / 96-191 and the two halves of the
+// last wave (two DPP rows each) take one layer each -- a narrow band leaves most FIR threads idle and the band-edge fit is
+// a fixed 3 us whatever the band, so two layers cost what one does.  Needs n_re <= (NCV / 2) * CV.
 template <int PAD, int CV>
-__device__ __forceinline__ void smooth_windowed(float2* Pl, int n_re, int n_pils, int pad_rt, const double* rcz,
-                                                float2* vpb, int tid, double vmx, double vin, double vid) {
+__device__ __forceinline__ void smooth_windowed(float2* Pl0, int ls, int nl, int n_re, int n_pils, int pad_rt, const double* rcz,
+                                                float2* vpb0, int tid, double vmx, double vin, double vid) {
   constexpr int NCV = NT - 64, NTAP = 2 * PAD + 1;
   // rc_ext[j], j = 0..NTAP-1: the actual taps centred in the PAD-wide template (zeros outside); the host lays the taps
   // out behind CE_CONV_C - 1 zeros (ce_plan.h: rcz)
   const double* rc = rcz + (CE_CONV_C - 1) - (PAD - pad_rt);
-  const int m0 = tid * CV;
+  const bool two = nl == 2;
+  // FIR threads: layer (tid >= NCV/2) with two layers; last wave: layer (lane >= 32)
+  const int sub = tid < NCV ? (two && tid >= NCV / 2 ? 1 : 0) : (two && tid - NCV >= 32 ? 1 : 0);
+  float2* Pl = Pl0 + sub * ls;
+  float2* vpb = vpb0 + sub * 32;
+  const int m0 = (tid - (tid < NCV ? sub * (NCV / 2) : 0)) * CV;
   double ar[CV], ai[CV];      // defined on the FIR threads only (not live across the virtual-pilot branch)
   double er = 0.0, ei = 0.0;  // edge output of this lane (last wave)
   int em = -1;
   if (tid >= NCV) {
-    const int q = tid - NCV;
+    const int q = (tid - NCV) - sub * 32;
     if (q < 32) {
       const int e = q >> 4;
       virtual_pilots(Pl, n_re, n_pils, e != 0, q & 15, vmx, vin, vid, [&](int dist, float2 val) { vpb[e * 16 + dist] = val; });
@@ -865,15 +873,21 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       constexpr int NB = 2 * CE_TA_HALF;
       const int nres = lh.ta_nres;
       const uint16_t* inv = ta_inv + lh.ta_inv_off;
-      const int ri = tid >> 4, a4 = tid & 15;
+      // Two layers at a time (plan: ta_lp == 2; 2-4 layers, at most 8 pilot-carrying residues, LDS to spare without
+      // costing a workgroup per CU): threads 0-127 transform layer l0, threads 128-255 layer l0 + 1, each into its own
+      // residue blocks; the bin sums then add the layers' powers in layer order, as the one-at-a-time form does.
+      const int lpn = (L >= 2) ? lp->ta_lp : 1;
+      const int sub = (lpn == 2) ? (tid >> 7) : 0;
+      const int ri = (lpn == 2) ? ((tid >> 4) & 7) : (tid >> 4), a4 = tid & 15;
+      float2* scr = scratch + sub * (8 * CE_TA_ROW);
       const unsigned long long res_packed = lh.ta_res_packed;
-      auto bin_power = [&](int k) -> float {
+      auto bin_power = [&](int k, const float2* blocks) -> float {
         const int q = k & 255, off = (q & 15) * 17 + (q >> 4);
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll 4
         for (int i = 0; i < nres; ++i) {  // (same order of additions whatever the unrolling: bit-identical)
           const int m = ((int)((res_packed >> (4 * i)) & 15u) * k) & (CE_FFT_SIZE - 1);  // W4096^(r k)
-          acc = cadd(acc, cmul(cmul(tw256[m >> 4], tw16[m & 15]), scratch[i * CE_TA_ROW + off]));
+          acc = cadd(acc, cmul(cmul(tw256[m >> 4], tw16[m & 15]), blocks[i * CE_TA_ROW + off]));
         }
         return acc.x * acc.x + acc.y * acc.y;
       };
@@ -890,9 +904,11 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         return idx == 0xFFFFu ? -1 : (int)idx;
       };
 #pragma unroll 1
-      for (int l = 0; l < L; ++l) {
+      for (int l0 = 0; l0 < L; l0 += lpn) {
+        const int l = l0 + sub;
         const float2* Pl = Ph + l * n_re_pad;
-        if (ri < nres) {  // pass 1: DFT16 over b of x[r + 16 a + 256 b], times W256^(a c)
+        const bool unit = ri < nres && l < L;
+        if (unit) {  // pass 1: DFT16 over b of x[r + 16 a + 256 b], times W256^(a c)
           const int r = (int)((res_packed >> (4 * ri)) & 15u);
           float2 v[16];
 #pragma unroll
@@ -901,14 +917,14 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
             v[b] = idx >= 0 ? Pl[idx] : make_float2(0.f, 0.f);
           }
           idft16(v);
-          float2* dst = scratch + ri * CE_TA_ROW + a4;
+          float2* dst = scr + ri * CE_TA_ROW + a4;
           dst[0] = v[0];
 #pragma unroll
           for (int c = 1; c < 16; ++c) dst[c * 17] = cmul(v[c], tw256[a4 * c]);
         }
         __syncthreads();
-        if (ri < nres) {  // pass 2 (in place): DFT16 over a for fixed c = a4 -> Y_r[c + 16 d] at [c*17 + d]
-          float2* rowp = scratch + ri * CE_TA_ROW + a4 * 17;
+        if (unit) {  // pass 2 (in place): DFT16 over a for fixed c = a4 -> Y_r[c + 16 d] at [c*17 + d]
+          float2* rowp = scr + ri * CE_TA_ROW + a4 * 17;
           float2 v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = rowp[i];
@@ -918,8 +934,12 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         }
         __syncthreads();
         STAMP(14);
-        if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0);
-        if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1);
+#pragma unroll 1
+        for (int s2 = 0; s2 < lpn && l0 + s2 < L; ++s2) {
+          const float2* blocks = scratch + s2 * (8 * CE_TA_ROW);
+          if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0, blocks);
+          if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1, blocks);
+        }
         __syncthreads();
         STAMP(15);
       }
@@ -1223,11 +1243,12 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       const int pad = rc_len / 2;
       const double vmx = lp->vp_mx, vin = lp->vp_inv_n, vid = lp->vp_inv_denom;
       if (lp->filt_windowed) {  // host sets it only for the 15-tap filter; other lengths take the generic form
-        float2* vpb = scratch;  // [2][16]: virtual pilot at distance e+1 beyond the head / tail edge
+        float2* vpb = scratch;  // [layer of the call][2][16]: virtual pilot at distance e+1 beyond the head / tail edge
+        constexpr int CVK = ce_conv_c(ND, KPT);
+        const int step = (L >= 2 && n_re <= ((NT - 64) / 2) * CVK) ? 2 : 1;  // two layers per call where the band leaves room
 #pragma unroll 1
-        for (int l = 0; l < L; ++l) {
-          float2* Pl = Ph + l * n_re_pad;
-          smooth_windowed<7, ce_conv_c(ND, KPT)>(Pl, n_re, n_pils, pad, rcz, vpb, tid, vmx, vin, vid);  // 15 taps: >= 3 PRB, comb 2
+        for (int l = 0; l < L; l += step) {
+          smooth_windowed<7, CVK>(Ph + l * n_re_pad, n_re_pad, min(step, L - l), n_re, n_pils, pad, rcz, vpb, tid, vmx, vin, vid);  // 15 taps: >= 3 PRB, comb 2
         }
       } else {
         // generic form (very wide bands): copy [virtual ; P ; virtual] to the scratch, one output per thread

@@ -65,6 +65,7 @@ struct alignas(16) CeDevPlan {
   int32_t filt_windowed, pad1;        // 1: n_re <= (CE_THREADS-64)*CE_CONV_C -> sliding-window FIR
   // ce_dl_cnn.py in-painting (interp == CE_INTERP_CNN): whole-band H per (hop, layer) in the scratch
   int32_t cnn_h_stride;               // complex elements between consecutive (hop, layer) H rows (band-relative: longest hop band, even)
+  int32_t ta_lp, pad_ta;              // layers the TA transform handles at a time (1, or 2: ce_estimate_kernel.h time_alignment)
   int32_t cnn_pong_off, cnn_gmax;     // byte offset of the second band buffer inside the scratch; longest run of unknown REs (iterated in-painting)
   int32_t cnn_n_max;                  // longest hop band (subcarriers)
   float cnn_alpha;                    // clamp(CNNSmoothingAlpha, 0, 1) (src/ce_dl_cnn.py:712-715)
