@@ -371,7 +371,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   // LDS scratch: TA residue blocks | virtual-pilot-extended band for the RC FIR | writer's H chunk
   {
     int need = 0;
-    for (int h = 0; h < d->n_hops; ++h) need = P.hop[h].ta_nres * CE_TA_ROW * 8 > need ? P.hop[h].ta_nres * CE_TA_ROW * 8 : need;
+    for (int h = 0; h < d->n_hops; ++h) need = P.hop[h].ta_nres * CE_TA_ROW * 8 > need ? P.hop[h].ta_nres * CE_TA_ROW * 8 : need;  // (the unpadded layout needs less: ta_lp below)
     if (d->smoothing == CE_SMOOTH_FILTER && P.ext_len * 8 > need) need = P.ext_len * 8;
     if (P.n_hops * L * 256 * 8 > need) need = P.n_hops * L * 256 * 8;
     if (d->smoothing == CE_SMOOTH_MMSE) {  // W^T (Re, Im) + X^T (Re, Im): [32][32] and [32][nbp] floats each
@@ -482,14 +482,20 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (d->smoothing == CE_SMOOTH_MMSE || (d->interp == CE_INTERP_CNN && !P.cnn_comb2)) P.feat = 3;
   if (P.feat == 3 && P.reg_nd > 0 && !ce_reg_has_ext(P.n_hops, P.reg_nd, P.reg_kpt)) P.reg_nd = 0;
 
-  // Two layers' TA transforms side by side (threads 128-255 are idle in the radix-16 passes when <= 8 residues carry pilots)
-  // where the second set of residue blocks fits the LDS share the multi-layer kernels' three workgroups per CU leave free
+  // Two TA transforms side by side -- the layers of a multi-layer hop, or the two hops of a one-layer item -- when at most 8
+  // residues carry pilots (threads 128-255 are idle in the radix-16 passes then) and the second set of residue blocks
+  // fits the LDS share that the kernel's register budget (ce_min_waves) leaves to a workgroup anyway
   P.ta_lp = 1;
-  if (L >= 2 && !getenv("CE_TA_LP1")) {  // env: A/B knob
+  {
     int nres_max = 0;
     for (int h = 0; h < d->n_hops; ++h) nres_max = std::max(nres_max, (int)P.hop[h].ta_nres);
-    const int sb2 = std::max(P.scratch_bytes, 2 * 8 * CE_TA_ROW * 8);
-    if (nres_max <= 8 && ce_lds_layout(P.n_hops, L, P.n_re_pad, sb2).total <= 53 * 1024) {
+    const int kpt = P.reg_nd ? P.reg_kpt : CE_KPT;
+    const bool late = ce_ta_late(L, P.n_hops, P.reg_nd, kpt, P.feat & 1);
+    const int sb2 = std::max(P.scratch_bytes, 2 * 8 * ce_ta_row(late) * 8);
+    const int waves = ce_min_waves(P.n_hops, P.reg_nd, kpt, P.feat & 1, L);
+    const bool shape = L >= 2 || (d->n_hops == 2 && late);
+    if (shape && !getenv("CE_TA_LP1") && nres_max <= 8 &&   // env: A/B knob
+        ((ce_lds_layout(P.n_hops, L, P.n_re_pad, sb2).total + 2047) & ~2047) * waves <= 160 * 1024) {  // LDS is granted in 2 KB steps (measured: 3 x 52 128 B fit a CU, 3 x 54 176 B do not)
       P.ta_lp = 2;
       P.scratch_bytes = sb2;
     }

@@ -36,70 +36,7 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_ABLATE
 #define CE_ABLATE 0   // timing experiments only (tools/ablate.py): 1 TA, 2 smoothing, 4 residual, 8 writer, 16 CFO, 32 input loads, 64 writer without LDS reads
 #endif
-#ifndef CE_MIN_WAVES
-#define CE_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for (3 workgroups per CU; 4 would spill)
-#endif
-#ifndef CE_MIN_WAVES_LIGHT
-#define CE_MIN_WAVES_LIGHT 3   // the same for single-hop register-path kernels built without the FIR ("none" / "mean" smoothing)
-#endif
-#ifndef CE_MIN_WAVES_L2H2
-#define CE_MIN_WAVES_L2H2 3   // re-read path, 2-4 layers x 2 hops (3: 4-11 spilled VGPRs; 2: none, but one workgroup less per CU on narrow bands)
-#endif
-#ifndef CE_MW3_LIMIT
-#define CE_MW3_LIMIT 14  // single hop: up to this many pilot REs x symbols per thread, 3 workgroups per CU (168 VGPRs)
-#endif
-#ifndef CE_MW5_LIMIT
-#define CE_MW5_LIMIT 2   // single hop: up to this many pilot REs x symbols per thread, 5 workgroups per CU (<= 96 VGPRs: the FIR shapes spill 1-2
-                         // registers for it and gain 10-14 % on <= 25-PRB hops; at 4 per thread the 6-8 spilled registers cost more than the fifth workgroup gives)
-#endif
-#ifndef CE_MW4_LIMIT
-#define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
-#endif
-#ifndef CE_NH2_MW4_LIMIT
-#define CE_NH2_MW4_LIMIT 2   // two hops: up to this many pilot REs x symbols per thread, 4 workgroups per CU (4-8 spilled VGPRs; measured +6..12 % on narrow hops, nothing at 4)
-#endif
-#ifndef CE_NH2_MW2_FROM
-#define CE_NH2_MW2_FROM 15  // two hops: from this many pilot REs x symbols per thread on, 2 workgroups per CU with everything in registers
-#endif
-// Feature set compiled into an instantiation (template parameter FEAT): a register-path kernel only carries the
-// smoothing code its plans run, so e.g. the headline kernel's register allocation is not shaped by the MFMA block
-// of the mmse extension or the iterated in-painting it never executes.
-//   CE_FEAT_FIR  the raised-cosine FIR with virtual pilots (Smoothing="filter", T:637-664) and the CNNSmoothingAlpha blend
-//   CE_FEAT_EXT  the unpinned mmse extension (MFMA) and ce_dl_cnn's iterated in-painting (masks without a closed form)
-// "none" / "mean" smoothing, both interpolation closed forms and every writer are in all kernels.
-constexpr int CE_FEAT_FIR = 1, CE_FEAT_EXT = 2;
-
-// Register budget of the register-path kernels by pilot REs x DM-RS symbols per thread (KPT * ND): workgroups per CU
-// the allocator must leave room for, and whether the DM-RS symbols stay in registers next to the received pilots
-// (otherwise the three stages that use them re-read them through L2).  The 3-symbol wide kernel measured 2.93 ms at
-// 2 workgroups per CU with everything in registers vs 3.23 ms at 3 with the symbols re-read (3.6 ms generic path).
-constexpr int ce_min_waves(int nh, int nd, int kpt, int feat, int layers = 1) {
-  const int n = nd * kpt;
-  if (nd == 0) return (layers >= 2 && nh == 2) ? CE_MIN_WAVES_L2H2 : CE_MIN_WAVES;
-  if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= CE_MW3_LIMIT ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
-  return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
-}
-constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
-  const int n = nd * kpt;
-  return nd > 0 && (nh == 1 || n <= 8 || n >= CE_NH2_MW2_FROM);
-}
-// Where the time-alignment stage runs: after the grid writer (the read -> estimate -> write chain of an item is shorter by
-// its longest stage, which then overlaps the draining stores), or inside the hop loop before it.  Same arithmetic either way.
-#ifndef CE_TA_LATE
-#define CE_TA_LATE -1   // -1: per-shape policy below; 0 / 1: force (A/B builds)
-#endif
-// Policy from interleaved same-box A/Bs of both placements over tools/perf_cases.py (profiles/round2_ta_placement_ab.txt;
-// resolution of the method ~2 %): late wins 1.5-3 % on the single-hop one-layer shapes, 3-6 % on narrow two-hop ones and
-// for 2-4 layers of one hop; early wins 5-10 % where only two workgroups fit a CU (3 symbols x CE_KPT REs in registers:
-// the late stage keeps a slot from its next item) and 4 % for 2 layers x 2 hops; the rest is within the resolution.
-constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
-  if (CE_TA_LATE >= 0) return CE_TA_LATE != 0;
-  if (nd > 0 && ce_min_waves(nh, nd, kpt, feat) == 2) return false;
-  if (layers >= 2 && nh == 2) return false;
-  // the widest shapes of the 4-workgroup tier (128 VGPRs) with the FIR compiled in: late placement would spill 1-4 registers
-  if (nh == 1 && nd * kpt == CE_MW4_LIMIT && (feat & CE_FEAT_FIR)) return false;
-  return true;
-}
+// (register budgets, feature sets and the TA placement policy: ce_plan.h -- the host sizes the LDS by the same rules)
 #ifndef CE_PF1_LIMIT
 #define CE_PF1_LIMIT 4    // two hops: up to this many pilot REs x symbols per thread, hop 2's pilots are prefetched with hop 1's
 #endif
@@ -377,6 +314,15 @@ __device__ __forceinline__ float2 lp3x2(const float2* x, int i, int n) {
   for (int d = 0; d < 3; ++d) lp3(x, reflect_idx(i - 1 + d, n), n, &r[d], &q[d]);
   return make_float2((float)((0.25 * r[0] + 0.5 * r[1]) + 0.25 * r[2]), (float)((0.25 * q[0] + 0.5 * q[1]) + 0.25 * q[2]));
 }
+
+// Element (row c, column d) of a 16 x 16 residue block of the TA transform.  The first pass writes columns, the second
+// reads and writes rows (a 16-element row stride would put a row access on two LDS banks).  Two layouts (ce_ta_row):
+// SWZ = false: rows of 17 (one padding column), immediate offsets from one address register; SWZ = true: unpadded, column
+// d ^ c -- 1 KB less per 8 residues, which is what lets a second set of blocks fit beside the first without costing a
+// workgroup per CU (time_alignment), but a computed address per element: +30 spilled VGPRs where the stage runs inside the
+// hop loop of the multi-layer two-hop kernels (-12 % there), so only the kernels that run it after the writer use it.
+template <bool SWZ>
+__device__ __forceinline__ int ta_at(int c, int d) { return SWZ ? c * 16 + (d ^ c) : c * 17 + d; }
 
 // One run of g <= G unknown REs between two pilots (or between a band edge and a pilot), iterated in registers exactly as
 // the reference iterates the whole band (C:489-505): x <- (0.25 x[i-1] + 0.5 x[i] + 0.25 x[i+1]) / (den + eps) in float64
@@ -682,6 +628,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool REG = ND > 0;
   constexpr bool TA_LATE = ce_ta_late(L, NH, ND, KPT, FEAT);
+  constexpr int TA_ROW = ce_ta_row(TA_LATE);   // complex elements per residue block of the TA transform (ta_at)
   constexpr int NC = (L + 1) / 2;
   const int tid0 = threadIdx.x;
   int tid = tid0;
@@ -859,35 +806,39 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
 
   // ------------------------------------------------------------ time alignment of one hop (S8)
   double tot_ta = 0.0;
-  auto time_alignment = [&](int h) {
+  // `npar` == 2 (one layer, two hops, plan: ta_lp == 2): hops h0 and h0 + 1 side by side -- threads 0-127 run hop h0's
+  // radix-16 passes, threads 128-255 hop h0 + 1's, into separate residue blocks -- then each hop's bins and arg-max in turn.
+  auto time_alignment = [&](int h0, int npar) {
     STAMP(9);
-    const CeDevHop& lh = lp->hop[h];
-    const float2* Ph = P + h * L * n_re_pad;
     // x[n] = P[k] at the pilot subcarriers of the LAST CDM group (for every layer, T:672-675), else 0;
     // X[k] = sum_n x[n] W^(nk), W = exp(+j 2 pi / 4096), wanted only for k in [0,144) U [3952,4096).
     // n = r + 16 n':  X[k] = sum_r W^(rk) Y_r[k mod 256],  Y_r = 256-point IDFT of x[r + 16 n'] done as
     // two radix-16 passes in LDS; residues r without pilots (half of them for a comb-2 DM-RS) are skipped.
     if (!(CE_ABLATE & 1)) {
-      float pw0 = 0.f, pw1 = 0.f;  // bins tid and tid + NT of the 288 examined (b < 144: delay side, else advance side)
-      const int b0 = tid, b1 = tid + NT;
+      const int b0 = tid, b1 = tid + NT;  // bins tid and tid + NT of the 288 examined (b < 144: delay side, else advance side)
       constexpr int NB = 2 * CE_TA_HALF;
-      const int nres = lh.ta_nres;
-      const uint16_t* inv = ta_inv + lh.ta_inv_off;
       // Two layers at a time (plan: ta_lp == 2; 2-4 layers, at most 8 pilot-carrying residues, LDS to spare without
       // costing a workgroup per CU): threads 0-127 transform layer l0, threads 128-255 layer l0 + 1, each into its own
       // residue blocks; the bin sums then add the layers' powers in layer order, as the one-at-a-time form does.
+      constexpr bool HPAR_OK = NH == 2 && L == 1 && TA_LATE;  // elsewhere the hop of the passes stays wave-uniform (scalar registers)
+      const bool hpar = HPAR_OK && npar == 2;
       const int lpn = (L >= 2) ? lp->ta_lp : 1;
-      const int sub = (lpn == 2) ? (tid >> 7) : 0;
-      const int ri = (lpn == 2) ? ((tid >> 4) & 7) : (tid >> 4), a4 = tid & 15;
-      float2* scr = scratch + sub * (8 * CE_TA_ROW);
+      const int sub = (lpn == 2 || hpar) ? (tid >> 7) : 0;
+      const int ri = (lpn == 2 || hpar) ? ((tid >> 4) & 7) : (tid >> 4), a4 = tid & 15;
+      float2* scr = scratch + sub * (8 * TA_ROW);
+      // the hop whose passes this thread runs
+      const CeDevHop& lh = lp->hop[h0 + (hpar ? sub : 0)];
+      const float2* Ph = P + (h0 + (hpar ? sub : 0)) * L * n_re_pad;
+      const int nres = lh.ta_nres;
+      const uint16_t* inv = ta_inv + lh.ta_inv_off;
       const unsigned long long res_packed = lh.ta_res_packed;
-      auto bin_power = [&](int k, const float2* blocks) -> float {
-        const int q = k & 255, off = (q & 15) * 17 + (q >> 4);
+      auto bin_power = [&](int k, const float2* blocks, int nr, unsigned long long resp) -> float {
+        const int q = k & 255, off = ta_at<TA_LATE>(q & 15, q >> 4);
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll 4
-        for (int i = 0; i < nres; ++i) {  // (same order of additions whatever the unrolling: bit-identical)
-          const int m = ((int)((res_packed >> (4 * i)) & 15u) * k) & (CE_FFT_SIZE - 1);  // W4096^(r k)
-          acc = cadd(acc, cmul(cmul(tw256[m >> 4], tw16[m & 15]), blocks[i * CE_TA_ROW + off]));
+        for (int i = 0; i < nr; ++i) {  // (same order of additions whatever the unrolling: bit-identical)
+          const int m = ((int)((resp >> (4 * i)) & 15u) * k) & (CE_FFT_SIZE - 1);  // W4096^(r k)
+          acc = cadd(acc, cmul(cmul(tw256[m >> 4], tw16[m & 15]), blocks[i * TA_ROW + off]));
         }
         return acc.x * acc.x + acc.y * acc.y;
       };
@@ -903,9 +854,46 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         const unsigned idx = inv[n];
         return idx == 0xFFFFu ? -1 : (int)idx;
       };
+      // arg-max with first-index tie break on each side: key = (power bits, ~index); adds the hop's seconds to tot_ta
+      auto arg_max = [&](int h, float pw0, float pw1) {
+        unsigned long long kh = 0ull, kt = 0ull;
+        auto offer = [&](int b, float pw) {
+          if (b < NB) {
+            const int idx = b < CE_TA_HALF ? b : b - CE_TA_HALF;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(pw) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
+            if (b < CE_TA_HALF) kh = key > kh ? key : kh;
+            else kt = key > kt ? key : kt;
+          }
+        };
+        offer(b0, pw0);
+        offer(b1, pw1);
+        kh = wave_max_u64(kh);
+        kt = wave_max_u64(kt);
+        unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 48);  // own slot
+        if ((tid & 63) == 0) {
+          ared[(tid >> 6) * 2] = kh;
+          ared[(tid >> 6) * 2 + 1] = kt;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned long long mh = 0ull, mt = 0ull;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            mh = ared[2 * w] > mh ? ared[2 * w] : mh;
+            mt = ared[2 * w + 1] > mt ? ared[2 * w + 1] : mt;
+          }
+          const float vd = __uint_as_float((unsigned)(mh >> 32)), va = __uint_as_float((unsigned)(mt >> 32));
+          const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
+          const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
+          const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
+          tot_ta += (double)i_max / (double)CE_FFT_SIZE / lp->scs;  // T:698, the reference's two float64 divisions
+          if (a.stage_s) a.stage_s[(item * NH + h) * 2 + 1] = (double)i_max;
+        }
+      };
+      float pw0 = 0.f, pw1 = 0.f;
 #pragma unroll 1
       for (int l0 = 0; l0 < L; l0 += lpn) {
-        const int l = l0 + sub;
+        const int l = l0 + (hpar ? 0 : sub);
         const float2* Pl = Ph + l * n_re_pad;
         const bool unit = ri < nres && l < L;
         if (unit) {  // pass 1: DFT16 over b of x[r + 16 a + 256 b], times W256^(a c)
@@ -917,65 +905,47 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
             v[b] = idx >= 0 ? Pl[idx] : make_float2(0.f, 0.f);
           }
           idft16(v);
-          float2* dst = scr + ri * CE_TA_ROW + a4;
-          dst[0] = v[0];
+          float2* blk = scr + ri * TA_ROW;
+          blk[ta_at<TA_LATE>(0, a4)] = v[0];
 #pragma unroll
-          for (int c = 1; c < 16; ++c) dst[c * 17] = cmul(v[c], tw256[a4 * c]);
+          for (int c = 1; c < 16; ++c) blk[ta_at<TA_LATE>(c, a4)] = cmul(v[c], tw256[a4 * c]);
         }
         __syncthreads();
-        if (unit) {  // pass 2 (in place): DFT16 over a for fixed c = a4 -> Y_r[c + 16 d] at [c*17 + d]
-          float2* rowp = scr + ri * CE_TA_ROW + a4 * 17;
+        if (unit) {  // pass 2 (in place): DFT16 over a for fixed c = a4 -> Y_r[c + 16 d] at element (c, d)
+          float2* blk = scr + ri * TA_ROW;
           float2 v[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = rowp[i];
+          for (int i = 0; i < 16; ++i) v[i] = blk[ta_at<TA_LATE>(a4, i)];
           idft16(v);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) rowp[i] = v[i];
+          for (int i = 0; i < 16; ++i) blk[ta_at<TA_LATE>(a4, i)] = v[i];
         }
         __syncthreads();
         STAMP(14);
+        if (!hpar) {
+          const CeDevHop& bh = lp->hop[h0];
 #pragma unroll 1
-        for (int s2 = 0; s2 < lpn && l0 + s2 < L; ++s2) {
-          const float2* blocks = scratch + s2 * (8 * CE_TA_ROW);
-          if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0, blocks);
-          if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1, blocks);
+          for (int s2 = 0; s2 < lpn && l0 + s2 < L; ++s2) {
+            const float2* blocks = scratch + s2 * (8 * TA_ROW);
+            if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0, blocks, bh.ta_nres, bh.ta_res_packed);
+            if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1, blocks, bh.ta_nres, bh.ta_res_packed);
+          }
+          __syncthreads();
         }
-        __syncthreads();
         STAMP(15);
       }
-      // arg-max with first-index tie break on each side: key = (power bits, ~index)
-      unsigned long long kh = 0ull, kt = 0ull;
-      auto offer = [&](int b, float pw) {
-        if (b < NB) {
-          const int idx = b < CE_TA_HALF ? b : b - CE_TA_HALF;
-          const unsigned long long key = ((unsigned long long)__float_as_uint(pw) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
-          if (b < CE_TA_HALF) kh = key > kh ? key : kh;
-          else kt = key > kt ? key : kt;
+      if (!hpar) {
+        arg_max(h0, pw0, pw1);
+      } else {
+#pragma unroll 1
+        for (int s2 = 0; s2 < 2; ++s2) {  // one layer: each hop's bins straight from its blocks
+          const CeDevHop& bh = lp->hop[h0 + s2];
+          const float2* blocks = scratch + s2 * (8 * TA_ROW);
+          const float q0 = b0 < NB ? bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0, blocks, bh.ta_nres, bh.ta_res_packed) : 0.f;
+          const float q1 = b1 < NB ? bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1, blocks, bh.ta_nres, bh.ta_res_packed) : 0.f;
+          arg_max(h0 + s2, q0, q1);
+          __syncthreads();  // the next hop's arg-max reuses the key slots
         }
-      };
-      offer(b0, pw0);
-      offer(b1, pw1);
-      kh = wave_max_u64(kh);
-      kt = wave_max_u64(kt);
-      unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 48);  // own slot: no barrier needed after use
-      if ((tid & 63) == 0) {
-        ared[(tid >> 6) * 2] = kh;
-        ared[(tid >> 6) * 2 + 1] = kt;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        unsigned long long mh = 0ull, mt = 0ull;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          mh = ared[2 * w] > mh ? ared[2 * w] : mh;
-          mt = ared[2 * w + 1] > mt ? ared[2 * w + 1] : mt;
-        }
-        const float vd = __uint_as_float((unsigned)(mh >> 32)), va = __uint_as_float((unsigned)(mt >> 32));
-        const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
-        const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
-        const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
-        tot_ta += (double)i_max / (double)CE_FFT_SIZE / lp->scs;  // T:698, the reference's two float64 divisions
-        if (a.stage_s) a.stage_s[(item * NH + h) * 2 + 1] = (double)i_max;
       }
     }
   };
@@ -1369,7 +1339,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       tot_noise += v[1];
       tot_rsrp += lp->beta * lp->beta * v[2] * (double)n_dmrs;
     }
-    if constexpr (!TA_LATE) time_alignment(h);
+    if constexpr (!TA_LATE) time_alignment(h, 1);
   }
 
   STAMP(6);
@@ -1649,13 +1619,17 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
     // Nothing the grid needs depends on it, so it runs here, while this workgroup's stores drain: the read ->
     // estimate -> write chain of an item is shorter by this stage, the longest of the estimation.
     __syncthreads();  // the writers are done with the scratch
+    if (NH == 2 && L == 1 && lp->ta_lp == 2) {
+      time_alignment(0, 2);  // both hops' transforms side by side
+    } else {
 #pragma unroll 1
-    for (int h = 0; h < NH; ++h) {
-      if (NH > 1) {
-        tid = tid0;
-        asm volatile("" : "+v"(tid) : : "memory");
+      for (int h = 0; h < NH; ++h) {
+        if (NH > 1) {
+          tid = tid0;
+          asm volatile("" : "+v"(tid) : : "memory");
+        }
+        time_alignment(h, 1);
       }
-      time_alignment(h);
     }
   }
   if (tid == 0 && !(CE_ABLATE & 128)) a.ta[item] = (NH == 2) ? tot_ta / 2.0 : tot_ta;  // T:918-919

@@ -14,11 +14,80 @@
 #define CE_KPT (CE_THREADS == 256 ? 7 : 4)  // pilot REs per thread on the register path (n_re <= CE_KPT * CE_THREADS)
 #define CE_CONV_C 9         // consecutive RC-FIR outputs per thread (sliding window), conv threads = CE_THREADS - 64
 #define CE_RCZ_LEN (CE_MAX_RC_TAPS + 2 * (CE_CONV_C - 1))
-#define CE_TA_ROW 272       // 16 x 17 complex per residue block (padded against LDS bank conflicts)
+#define CE_TA_ROW 272       // largest residue block of the TA transform, complex elements (ce_ta_row)
 // the twiddle buffer (complex64 elements): exp(+j 2 pi m / 4096), m < 4096 | mmse W^T (extension) | the 272 twiddles the
 // TA transform uses, contiguous: W256^j = tw[16 j] (j < 256), then W4096^i = tw[i] (i < 16)
 #define CE_TWC_OFF (CE_FFT_SIZE + CE_MMSE_BLOCK * CE_MMSE_BLOCK)
 #define CE_TW_TOTAL (CE_TWC_OFF + 256 + 16)
+
+// ---- per-shape policies shared by the kernel template (launch bounds, stage order) and the host (LDS sizing) ----
+#ifndef CE_MIN_WAVES
+#define CE_MIN_WAVES 3   // waves per SIMD the register allocator must leave room for (3 workgroups per CU; 4 would spill)
+#endif
+#ifndef CE_MIN_WAVES_LIGHT
+#define CE_MIN_WAVES_LIGHT 3   // the same for single-hop register-path kernels built without the FIR ("none" / "mean" smoothing)
+#endif
+#ifndef CE_MIN_WAVES_L2H2
+#define CE_MIN_WAVES_L2H2 3   // re-read path, 2-4 layers x 2 hops (3: 4-11 spilled VGPRs; 2: none, but one workgroup less per CU on narrow bands)
+#endif
+#ifndef CE_MW3_LIMIT
+#define CE_MW3_LIMIT 14  // single hop: up to this many pilot REs x symbols per thread, 3 workgroups per CU (168 VGPRs)
+#endif
+#ifndef CE_MW5_LIMIT
+#define CE_MW5_LIMIT 2   // single hop: up to this many pilot REs x symbols per thread, 5 workgroups per CU (<= 96 VGPRs: the FIR shapes spill 1-2
+                         // registers for it and gain 10-14 % on <= 25-PRB hops; at 4 per thread the 6-8 spilled registers cost more than the fifth workgroup gives)
+#endif
+#ifndef CE_MW4_LIMIT
+#define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
+#endif
+#ifndef CE_NH2_MW4_LIMIT
+#define CE_NH2_MW4_LIMIT 2   // two hops: up to this many pilot REs x symbols per thread, 4 workgroups per CU (4-8 spilled VGPRs; measured +6..12 % on narrow hops, nothing at 4)
+#endif
+#ifndef CE_NH2_MW2_FROM
+#define CE_NH2_MW2_FROM 15  // two hops: from this many pilot REs x symbols per thread on, 2 workgroups per CU with everything in registers
+#endif
+// Feature set compiled into an instantiation (template parameter FEAT): a register-path kernel only carries the
+// smoothing code its plans run, so e.g. the headline kernel's register allocation is not shaped by the MFMA block
+// of the mmse extension or the iterated in-painting it never executes.
+//   CE_FEAT_FIR  the raised-cosine FIR with virtual pilots (Smoothing="filter", T:637-664) and the CNNSmoothingAlpha blend
+//   CE_FEAT_EXT  the unpinned mmse extension (MFMA) and ce_dl_cnn's iterated in-painting (masks without a closed form)
+// "none" / "mean" smoothing, both interpolation closed forms and every writer are in all kernels.
+constexpr int CE_FEAT_FIR = 1, CE_FEAT_EXT = 2;
+
+// Register budget of the register-path kernels by pilot REs x DM-RS symbols per thread (KPT * ND): workgroups per CU
+// the allocator must leave room for, and whether the DM-RS symbols stay in registers next to the received pilots
+// (otherwise the three stages that use them re-read them through L2).  The 3-symbol wide kernel measured 2.93 ms at
+// 2 workgroups per CU with everything in registers vs 3.23 ms at 3 with the symbols re-read (3.6 ms generic path).
+constexpr int ce_min_waves(int nh, int nd, int kpt, int feat, int layers = 1) {
+  const int n = nd * kpt;
+  if (nd == 0) return (layers >= 2 && nh == 2) ? CE_MIN_WAVES_L2H2 : CE_MIN_WAVES;
+  if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= CE_MW3_LIMIT ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
+  return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
+}
+constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
+  const int n = nd * kpt;
+  return nd > 0 && (nh == 1 || n <= 8 || n >= CE_NH2_MW2_FROM);
+}
+// Where the time-alignment stage runs: after the grid writer (the read -> estimate -> write chain of an item is shorter by
+// its longest stage, which then overlaps the draining stores), or inside the hop loop before it.  Same arithmetic either way.
+#ifndef CE_TA_LATE
+#define CE_TA_LATE -1   // -1: per-shape policy below; 0 / 1: force (A/B builds)
+#endif
+// Policy from interleaved same-box A/Bs of both placements over tools/perf_cases.py (profiles/round2_ta_placement_ab.txt;
+// resolution of the method ~2 %): late wins 1.5-3 % on the single-hop one-layer shapes, 3-6 % on narrow two-hop ones and
+// for 2-4 layers of one hop; early wins 5-10 % where only two workgroups fit a CU (3 symbols x CE_KPT REs in registers:
+// the late stage keeps a slot from its next item) and 4 % for 2 layers x 2 hops; the rest is within the resolution.
+constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
+  if (CE_TA_LATE >= 0) return CE_TA_LATE != 0;
+  if (nd > 0 && ce_min_waves(nh, nd, kpt, feat) == 2) return false;
+  if (layers >= 2 && nh == 2) return false;
+  // the widest shapes of the 4-workgroup tier (128 VGPRs) with the FIR compiled in: late placement would spill 1-4 registers
+  if (nh == 1 && nd * kpt == CE_MW4_LIMIT && (feat & CE_FEAT_FIR)) return false;
+  return true;
+}
+// complex elements per 16 x 16 residue block of the TA transform: unpadded + swizzled where the stage runs after the writer,
+// 16 x 17 where it runs inside the hop loop (ce_estimate_kernel.h: ta_at)
+constexpr int ce_ta_row(bool late) { return late ? 256 : 272; }
 
 struct CeDevHop {
   int32_t n_dmrs;                     // DM-RS symbols in the hop
