@@ -642,8 +642,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   float2* scratch = reinterpret_cast<float2*>(smem + lay.off_scratch);   // scratch_bytes
   double* red = reinterpret_cast<double*>(smem + lay.off_red);
   float2* rot_final = reinterpret_cast<float2*>(smem + lay.off_rot);     // [16] exp(+j ph) of the final CFO
-  float2* rot_neg = rot_final + 16;                                      // [16] exp(-j ph) at the hop's DM-RS symbols
-  float2* rot_pos = rot_neg + 16;                                        // [16] exp(+j ph)
+  float2* rot_tab = rot_final + 16;                                      // per hop: [16] exp(-j ph) at the hop's DM-RS symbols, [16] exp(+j ph)
   float2* tab = reinterpret_cast<float2*>(smem + lay.off_tab);           // [NH][CDM][12] {alpha, bits(r_ord)}
   double* misc = reinterpret_cast<double*>(smem + lay.off_misc);         // [0..1] cfo_hop
   float2* tw256 = reinterpret_cast<float2*>(smem + lay.off_tw);          // [256] W256^j = exp(+j 2 pi j / 256)
@@ -957,20 +956,42 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   if (threadIdx.x == 0 && a.stamps) a.stamps[item * 16 + 13] = t_entry;
 #endif
 
+  // Narrow two-hop tiers (both hops' pilots in registers from the start): the hop loop runs twice -- pass 0: CFO, LS for
+  // hop 1 then hop 2; ONE smoothing call for both hops (their rows of P are adjacent: the two-layer form of the windowed
+  // FIR, whose band-edge stage costs the same for one row or two); pass 1: the residuals, hop 2 first (its pilots are the
+  // ones in `xr` after pass 0), then hop 1.  Same arithmetic per hop, two of the item's longest serial stages side by side.
+  // (Both hops' pilots then stay live across the FIR: beyond KPT x ND = 2 that costs the fourth workgroup per CU.)
+  constexpr bool FUSED2 = PF1 && KPT * ND <= 2;
+  constexpr int NPASS = FUSED2 ? 2 : 1;
+  constexpr int LSM = FUSED2 ? 2 : L;   // rows of P one smoothing invocation covers
+  float epre_h0 = 0.f, epre_h1 = 0.f;   // FUSED2: each hop's EPRE partial sum, carried from pass 0 to pass 1
+  auto swap_hops = [&]() __attribute__((always_inline)) {
+    if constexpr (PF1) {
+#pragma unroll
+      for (int i = 0; i < (REG ? KPT * ND : 1); ++i) { const float2 t = xr[i]; xr[i] = xr1[i]; xr1[i] = t; }
+#pragma unroll
+      for (int i = 0; i < (PREG ? KPT * ND * L : 1); ++i) { const float2 t = pr[i]; pr[i] = pr1[i]; pr1[i] = t; }
+    }
+  };
 #pragma unroll 1
-  for (int h = 0; h < NH; ++h) {
+  for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll 1
+  for (int hi = 0; hi < NH; ++hi) {
+    const int h = (FUSED2 && pass == 1) ? NH - 1 - hi : hi;
+    const bool front = !FUSED2 || pass == 0, back = !FUSED2 || pass == 1;
     const CeDevHop& hp = plan->hop[h];  // global copy: load + CFO stages (before the first barrier)
     const CeDevHop& lh = lp->hop[h];    // LDS copy: everything after
     float2* Ph = P + h * L * n_re_pad;
+    float2* rot_neg = rot_tab + h * 32;
+    float2* rot_pos = rot_neg + 16;
     const int n_dmrs = REG ? ND : hp.n_dmrs;
     const float n_dmrs_f = (float)n_dmrs;
     const bool has_cfo = REG ? (ND >= 2) : (hp.has_cfo != 0);
+    float epre_part = 0.f;
+    if (front) {
     if (h > 0) {
       if constexpr (PF1) {
-#pragma unroll
-        for (int i = 0; i < (REG ? KPT * ND : 1); ++i) xr[i] = xr1[i];
-#pragma unroll
-        for (int i = 0; i < (PREG ? KPT * ND * L : 1); ++i) pr[i] = pr1[i];
+        swap_hops();  // hop 2's pilots were requested together with hop 1's
       } else {
         load_hop(item, h, xr, pr);
       }
@@ -1066,7 +1087,6 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
 
     STAMP(3);
     // ------------------------------------------------------------ EPRE, LS, DM-RS average (S2, S3, S5)
-    float epre_part = 0.f;
     if constexpr (REG) {
 #pragma unroll
       for (int i = 0; i < KPT; ++i) {
@@ -1127,27 +1147,38 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       __syncthreads();
     }
     dump_stage(0, h);
+    if (FUSED2) { if (h == 0) epre_h0 = epre_part; else epre_h1 = epre_part; }
+    }  // front
+    if (FUSED2 && back) {
+      if (h == 0) swap_hops();  // hop 1's pilots back into `xr` (pass 0 left hop 2's there)
+      pil_sym0_h = lh.pil_sym0;
+      epre_part = h == 0 ? epre_h0 : epre_h1;
+      tid = tid0;
+      asm volatile("" : "+v"(tid) : : "memory");
+    }
 
     STAMP(4);
     // ------------------------------------------------------------ frequency smoothing (S7)
-    if (CE_ABLATE & 2) {
+    // (FUSED2: once, after the second hop's LS, over both hops' rows)
+    float2* Psm = FUSED2 ? P : Ph;
+    if ((CE_ABLATE & 2) || (FUSED2 && !(pass == 0 && hi == NH - 1))) {
     } else if (lp->smoothing == CE_SMOOTH_MEAN) {
-      double m[2 * L];
+      double m[2 * LSM];
 #pragma unroll
-      for (int i = 0; i < 2 * L; ++i) m[i] = 0.0;
+      for (int i = 0; i < 2 * LSM; ++i) m[i] = 0.0;
       for (int k = tid; k < n_re; k += NT) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-          const float2 v = Ph[l * n_re_pad + k];
+        for (int l = 0; l < LSM; ++l) {
+          const float2 v = Psm[l * n_re_pad + k];
           m[2 * l] += (double)v.x;
           m[2 * l + 1] += (double)v.y;
         }
       }
-      block_sum<2 * L>(m, red);
+      block_sum<2 * LSM>(m, red);
       for (int k = tid; k < n_re; k += NT) {
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-          Ph[l * n_re_pad + k] = make_float2((float)(m[2 * l] / (double)n_re), (float)(m[2 * l + 1] / (double)n_re));
+        for (int l = 0; l < LSM; ++l)
+          Psm[l * n_re_pad + k] = make_float2((float)(m[2 * l] / (double)n_re), (float)(m[2 * l + 1] / (double)n_re));
       }
       __syncthreads();
     } else if ((FEAT & CE_FEAT_EXT) && lp->smoothing == CE_SMOOTH_MMSE) {
@@ -1214,28 +1245,28 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       const double vmx = lp->vp_mx, vin = lp->vp_inv_n, vid = lp->vp_inv_denom;
       if (lp->filt_windowed) {  // host sets it only for the 15-tap filter; other lengths take the generic form
         float2* vpb = scratch;  // [layer of the call][2][16]: virtual pilot at distance e+1 beyond the head / tail edge
-        constexpr int CVK = ce_conv_c(ND, KPT);
-        const int step = (L >= 2 && n_re <= ((NT - 64) / 2) * CVK) ? 2 : 1;  // two layers per call where the band leaves room
+        constexpr int CVK = FUSED2 ? (KPT == 1 ? 3 : 6) : ce_conv_c(ND, KPT);  // FUSED2: 96 FIR threads per row must cover KPT * 256 pilots
+        const int step = (LSM >= 2 && n_re <= ((NT - 64) / 2) * CVK) ? 2 : 1;  // two layers per call where the band leaves room
 #pragma unroll 1
-        for (int l = 0; l < L; l += step) {
-          smooth_windowed<7, CVK>(Ph + l * n_re_pad, n_re_pad, min(step, L - l), n_re, n_pils, pad, rcz, vpb, tid, vmx, vin, vid);  // 15 taps: >= 3 PRB, comb 2
+        for (int l = 0; l < LSM; l += step) {
+          smooth_windowed<7, CVK>(Psm + l * n_re_pad, n_re_pad, min(step, LSM - l), n_re, n_pils, pad, rcz, vpb, tid, vmx, vin, vid);  // 15 taps: >= 3 PRB, comb 2
         }
       } else {
         // generic form (very wide bands): copy [virtual ; P ; virtual] to the scratch, one output per thread
         const int ext_len = lp->ext_len, lpp = lp->filt_lpp;
 #pragma unroll 1
-        for (int l0 = 0; l0 < L; l0 += lpp) {
-          const int nl = min(lpp, L - l0);
+        for (int l0 = 0; l0 < LSM; l0 += lpp) {
+          const int nl = min(lpp, LSM - l0);
           if (tid < nl * 32) {
             const int g = tid >> 4;
             float2* ext = scratch + (g >> 1) * ext_len;
             const bool tail = (g & 1) != 0;
-            virtual_pilots(Ph + (l0 + (g >> 1)) * n_re_pad, n_re, n_pils, tail, tid & 15, vmx, vin, vid,
+            virtual_pilots(Psm + (l0 + (g >> 1)) * n_re_pad, n_re, n_pils, tail, tid & 15, vmx, vin, vid,
                            [&](int dist, float2 val) { ext[tail ? n_pils + n_re + dist : n_pils - 1 - dist] = val; });
           }
           for (int i = tid; i < nl * n_re; i += NT) {
             const int ll = i / n_re, k = i - ll * n_re;
-            scratch[ll * ext_len + n_pils + k] = Ph[(l0 + ll) * n_re_pad + k];
+            scratch[ll * ext_len + n_pils + k] = Psm[(l0 + ll) * n_re_pad + k];
           }
           __syncthreads();
           for (int i = tid; i < nl * n_re; i += NT) {
@@ -1251,7 +1282,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
                 ai += w * (double)v.y;
               }
             }
-            Ph[(l0 + ll) * n_re_pad + m] = make_float2((float)ar, (float)ai);
+            Psm[(l0 + ll) * n_re_pad + m] = make_float2((float)ar, (float)ai);
           }
           __syncthreads();
         }
@@ -1260,8 +1291,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         // optional blend with one low-pass pass over the smoothed pilots (src/ce_dl_cnn.py:712-715)
         const float al = lp->cnn_alpha;
 #pragma unroll 1
-        for (int l = 0; l < L; ++l) {
-          float2* Pl = Ph + l * n_re_pad;
+        for (int l = 0; l < LSM; ++l) {
+          float2* Pl = Psm + l * n_re_pad;
           for (int k = tid; k < n_re; k += NT) {
             const float2 rcv = Pl[k];
             float2 sm = rcv;
@@ -1279,6 +1310,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       }
     }
 
+    if (back) {
     dump_stage(1, h);
     STAMP(5);
     // ------------------------------------------------------------ residual noise, RSRP (S9, S11)
@@ -1340,7 +1372,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       tot_rsrp += lp->beta * lp->beta * v[2] * (double)n_dmrs;
     }
     if constexpr (!TA_LATE) time_alignment(h, 1);
+    }  // back
   }
+  }  // passes
 
   STAMP(6);
   STAMP(7);
