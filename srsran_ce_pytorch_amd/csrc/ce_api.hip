@@ -500,6 +500,24 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       P.scratch_bytes = sb2;
     }
   }
+  // Register-path kernels that cannot also hold the DM-RS symbols in registers (ce_pilots_in_regs) park the current hop's
+  // in the scratch behind whatever the smoothing stage uses there, when that fits the kernel's LDS share
+  P.pil_stash = 0;
+  if (P.reg_nd >= 2 && !ce_pilots_in_regs(P.n_hops, P.reg_nd, P.reg_kpt) && !getenv("CE_NO_PIL_STASH")) {  // env: A/B knob
+    int smooth_need = 512;  // windowed FIR: virtual pilots of up to two rows
+    if (d->smoothing == CE_SMOOTH_FILTER && !P.filt_windowed) smooth_need = P.filt_lpp * P.ext_len * 8;
+    if (d->interp == CE_INTERP_CNN && P.cnn_alpha > 0.f) smooth_need = std::max(smooth_need, n_re * 8);
+    smooth_need = (smooth_need + 15) & ~15;
+    const int waves = ce_min_waves(P.n_hops, P.reg_nd, P.reg_kpt, P.feat & 1, L);
+    for (int nd_st = P.reg_nd; nd_st >= 1; --nd_st) {  // as many of the hop's symbols as fit; the rest is re-read in the residual stage
+      const int sb = std::max(P.scratch_bytes, smooth_need + nd_st * L * P.n_re_pad * 8);
+      if (((ce_lds_layout(P.n_hops, L, P.n_re_pad, sb).total + 2047) & ~2047) * waves <= 160 * 1024) {
+        P.pil_stash = (smooth_need / 8) | (nd_st << 24);
+        P.scratch_bytes = sb;
+        break;
+      }
+    }
+  }
   CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
   if (const char* pad = getenv("CE_LDS_PAD_BYTES")) lay.total += atoi(pad) & ~15;  // tuning knob: lowers the workgroups resident per CU
   if (lay.total > 160 * 1024) { delete p; return fail(CE_ERR_UNSUPPORTED, "plan needs %d B of LDS (> 160 KiB)", lay.total); }

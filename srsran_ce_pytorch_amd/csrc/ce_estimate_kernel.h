@@ -674,6 +674,14 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   // them, so they come from L2
   constexpr bool PREG = ce_pilots_in_regs(NH, ND, KPT);
   float2 pr[PREG ? KPT * ND * L : 1];
+  // !PREG (two hops, 9-14 pilot REs x symbols per thread): every stage that needs the DM-RS symbols would fetch them again,
+  // and under load a fetch queues behind the chip-wide store stream for microseconds.  They are fetched ONCE per hop: the
+  // products rx * conj(pilot) that both the CFO and the LS stage start from are kept from the one to the other, and the
+  // symbols themselves wait for the residual stage in the LDS scratch (plan: pil_stash; each thread reads back what it wrote).
+  constexpr bool YK = REG && !PREG && ND >= 2;
+  float2 yk[YK ? KPT * ND * L : 1];
+  const int pil_stash_f = YK ? plan->pil_stash : 0;
+  const int pil_stash = pil_stash_f & 0xFFFFFF, stash_nd = pil_stash_f >> 24;   // offset in the scratch; symbols parked (the rest is re-read)
   // Two hops on the narrow tiers: the second hop's pilots are requested together with the first's (a few registers
   // more) instead of after the first hop's stages -- one memory round trip less in a latency-bound item.
   constexpr bool PF1 = REG && NH == 2 && KPT * ND <= CE_PF1_LIMIT;
@@ -1009,6 +1017,36 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
     STAMP(1);
     // ------------------------------------------------------------ CFO of the hop (S4)
     double cfo_hop = 0.0;
+    if constexpr (YK) {
+      float2 pt[KPT * ND * L];
+#pragma unroll
+      for (int i = 0; i < KPT; ++i)
+#pragma unroll
+        for (int s = 0; s < ND; ++s)
+#pragma unroll
+          for (int l = 0; l < L; ++l) pt[(i * ND + s) * L + l] = pilot_of(hp, i, s, l);
+      if (pil_stash) {
+        float2* st = scratch + pil_stash;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+          const int k = tid + i * NT;
+          if (k < n_re) {
+#pragma unroll
+            for (int s = 0; s < ND; ++s)
+              if (s < stash_nd) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) st[(s * L + l) * n_re_pad + k] = pt[(i * ND + s) * L + l];
+              }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < KPT; ++i)
+#pragma unroll
+        for (int s = 0; s < ND; ++s)
+#pragma unroll
+          for (int l = 0; l < L; ++l) yk[(i * ND + s) * L + l] = cmul_conj(xr[i * ND + s], pt[(i * ND + s) * L + l]);
+    }
     if (has_cfo && !(CE_ABLATE & 16)) {
       double acc[2 * L];
 #pragma unroll
@@ -1021,8 +1059,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         for (int i = 0; i < KPT; ++i) {
 #pragma unroll
           for (int l = 0; l < L; ++l) {
-            const float2 r0 = cmul_conj(xr[i * ND], pilot_of(hp, i, 0, l));
-            const float2 r1 = cmul_conj(xr[i * ND + 1], pilot_of(hp, i, 1, l));
+            const float2 r0 = YK ? yk[(i * ND) * L + l] : cmul_conj(xr[i * ND], pilot_of(hp, i, 0, l));
+            const float2 r1 = YK ? yk[(i * ND + 1) * L + l] : cmul_conj(xr[i * ND + 1], pilot_of(hp, i, 1, l));
             const float2 in = cmul_conj(r1, r0);  // conj(r0) * r1
             part[2 * l] += in.x;
             part[2 * l + 1] += in.y;
@@ -1100,7 +1138,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
           epre_part += x.x * x.x + x.y * x.y;
           const float2 rn = rot_neg[s];
 #pragma unroll
-          for (int l = 0; l < L; ++l) acc[l] = cadd(acc[l], cmul(cmul_conj(x, pilot_of(lh, i, s, l)), rn));
+          for (int l = 0; l < L; ++l) acc[l] = cadd(acc[l], cmul(YK ? yk[(i * ND + s) * L + l] : cmul_conj(x, pilot_of(lh, i, s, l)), rn));
         }
         if (k < n_re) {
 #pragma unroll
@@ -1317,6 +1355,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
     {
       float noise_part = 0.f, rsrp_part = 0.f;
       if constexpr (REG && !CE_RELOAD_RESID) {
+        const float2* stash_p = scratch + pil_stash;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
           const int k = tid + i * NT;
@@ -1332,7 +1371,16 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
               const float2 rp = rot_pos[s];
               float2 est = make_float2(0.f, 0.f);
 #pragma unroll
-              for (int l = 0; l < L; ++l) est = cadd(est, cmul(pilot_of(lh, i, s, l), cmul(hl[l], rp)));
+              for (int l = 0; l < L; ++l) {
+                float2 pv;
+                if (YK && s < stash_nd) {   // (two separate loads: one select over an LDS and a global address would be a flat load)
+                  pv = stash_p[(s * L + l) * n_re_pad + k];
+                  pin(pv);
+                } else {
+                  pv = pilot_of(lh, i, s, l);
+                }
+                est = cadd(est, cmul(pv, cmul(hl[l], rp)));
+              }
               const float dr = xr[i * ND + s].x - beta_f * est.x, di = xr[i * ND + s].y - beta_f * est.y;
               noise_part += dr * dr + di * di;
             }

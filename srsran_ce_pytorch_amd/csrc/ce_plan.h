@@ -43,8 +43,13 @@
 #ifndef CE_NH2_MW4_LIMIT
 #define CE_NH2_MW4_LIMIT 2   // two hops: up to this many pilot REs x symbols per thread, 4 workgroups per CU (4-8 spilled VGPRs; measured +6..12 % on narrow hops, nothing at 4)
 #endif
+#ifndef CE_NH1_PREG_LIMIT
+#define CE_NH1_PREG_LIMIT 99  // single hop: up to this many pilot REs x symbols per thread the DM-RS symbols stay in registers too
+#endif
 #ifndef CE_NH2_MW2_FROM
-#define CE_NH2_MW2_FROM 15  // two hops: from this many pilot REs x symbols per thread on, 2 workgroups per CU with everything in registers
+#define CE_NH2_MW2_FROM 22  // two hops: from this many pilot REs x symbols per thread on, 2 workgroups per CU with everything in registers
+                            // (no shape reaches it: with the DM-RS symbols fetched once per hop and parked in the LDS, three
+                            // workgroups per CU beat two with everything in registers -- 3 symbols x 200 PRB: 4.09 -> 3.37 ms)
 #endif
 // Feature set compiled into an instantiation (template parameter FEAT): a register-path kernel only carries the
 // smoothing code its plans run, so e.g. the headline kernel's register allocation is not shaped by the MFMA block
@@ -56,8 +61,9 @@ constexpr int CE_FEAT_FIR = 1, CE_FEAT_EXT = 2;
 
 // Register budget of the register-path kernels by pilot REs x DM-RS symbols per thread (KPT * ND): workgroups per CU
 // the allocator must leave room for, and whether the DM-RS symbols stay in registers next to the received pilots
-// (otherwise the three stages that use them re-read them through L2).  The 3-symbol wide kernel measured 2.93 ms at
-// 2 workgroups per CU with everything in registers vs 3.23 ms at 3 with the symbols re-read (3.6 ms generic path).
+// (otherwise they are fetched once per hop, the CFO and LS stages share the products rx * conj(pilot), and the residual
+// stage reads them back from the LDS scratch: plan pil_stash).  The single-hop 3-symbol wide kernel measured 2.80 ms at
+// 2 workgroups per CU with everything in registers vs 2.93 ms at 3 with the symbols parked; two hops the other way round.
 constexpr int ce_min_waves(int nh, int nd, int kpt, int feat, int layers = 1) {
   const int n = nd * kpt;
   if (nd == 0) return (layers >= 2 && nh == 2) ? CE_MIN_WAVES_L2H2 : CE_MIN_WAVES;
@@ -66,7 +72,7 @@ constexpr int ce_min_waves(int nh, int nd, int kpt, int feat, int layers = 1) {
 }
 constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
   const int n = nd * kpt;
-  return nd > 0 && (nh == 1 || n <= 8 || n >= CE_NH2_MW2_FROM);
+  return nd > 0 && (nh == 1 ? n <= CE_NH1_PREG_LIMIT : (n <= 8 || n >= CE_NH2_MW2_FROM));
 }
 // Where the time-alignment stage runs: after the grid writer (the read -> estimate -> write chain of an item is shorter by
 // its longest stage, which then overlaps the draining stores), or inside the hop loop before it.  Same arithmetic either way.
@@ -134,7 +140,9 @@ struct alignas(16) CeDevPlan {
   int32_t filt_windowed, pad1;        // 1: n_re <= (CE_THREADS-64)*CE_CONV_C -> sliding-window FIR
   // ce_dl_cnn.py in-painting (interp == CE_INTERP_CNN): whole-band H per (hop, layer) in the scratch
   int32_t cnn_h_stride;               // complex elements between consecutive (hop, layer) H rows (band-relative: longest hop band, even)
-  int32_t ta_lp, pad_ta;              // layers the TA transform handles at a time (1, or 2: ce_estimate_kernel.h time_alignment)
+  int32_t ta_lp, pil_stash;           // layers the TA transform handles at a time (1, or 2: ce_estimate_kernel.h time_alignment);
+                                      // pil_stash > 0: register-path kernels that cannot keep the DM-RS symbols in registers park the
+                                      // current hop's at this complex-element offset of the scratch instead of re-reading them per stage
   int32_t cnn_pong_off, cnn_gmax;     // byte offset of the second band buffer inside the scratch; longest run of unknown REs (iterated in-painting)
   int32_t cnn_n_max;                  // longest hop band (subcarriers)
   float cnn_alpha;                    // clamp(CNNSmoothingAlpha, 0, 1) (src/ce_dl_cnn.py:712-715)
