@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "ce_plan.h"
 
@@ -37,6 +38,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #define CE_ABLATE 0   // timing experiments only (tools/ablate.py): 1 TA, 2 smoothing, 4 residual, 8 writer, 16 CFO, 32 input loads, 64 writer without LDS reads
 #endif
 // (register budgets, feature sets and the TA placement policy: ce_plan.h -- the host sizes the LDS by the same rules)
+#ifndef CE_WR_UNROLL
+#define CE_WR_UNROLL 4    // direct writer: iterations whose LDS reads are requested together
+#endif
 #ifndef CE_PF1_LIMIT
 #define CE_PF1_LIMIT 4    // two hops: up to this many pilot REs x symbols per thread, hop 2's pilots are prefetched with hop 1's
 #endif
@@ -553,7 +557,7 @@ __device__ constexpr bool direct_ok() { return SC_STEP % 12 == 0; }  // whole-PR
 // inside the PRB -- hence its interpolation weight and anchor ordinals (T:325-337) -- is constant too:
 // interpolate straight from P in LDS (left + alpha (right - left), also AT pilots, as the reference does), no
 // staging buffer, no barrier.
-template <int L, int NH>
+template <int L, int NH, int WRU>
 __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ plan, const float2* P, const float2* tab,
                                                   const float2* rot_final, float4* out4, int n_re, int n_re_pad, int tid) {
   constexpr int ROW4 = 7 * L, ACTIVE = (NT / 252) * 252, SC_STEP = ACTIVE / ROW4, QS = SC_STEP / 12;
@@ -584,11 +588,27 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
     ro[e] = q[e] * hp.dpp[c] + __float_as_int(t.y);
     tail_r[e] = 12 * (hp.n_prbs - 1) + r12 >= hp.last_idx[c];
   }
+  // One hop: the iterations in which any lane of the wave is inside the hop's band form one interval [it_lo, it_hi) -- a
+  // wave's lanes span at most two PRBs and move up by QS PRBs per iteration.  Outside it the wave stores zeros and does
+  // nothing else; inside, the body is branch-free (per-lane selects), so that the unrolled iterations' LDS reads are
+  // requested together instead of one exec-masked region after the other.  (Two hops with different bands: the union of
+  // the lanes' intervals is nearly everything, and the per-element branches measured faster under load.)  WRU = unrolled
+  // iterations of the branch-free body, 0 = per-element branches (profiles/round2_writer_ab.txt).
+  int it_lo = 0, it_hi = 0;
+  if constexpr (NH == 1 && WRU > 0) {
+    // lane-wise: first iteration with q >= 0, one past the last with q < n_prbs (q = q[0] + it * QS); the wave's interval
+    // starts with its LAST lane's (largest subcarrier) and ends with its FIRST lane's
+    const int q0 = q[0], np = nprb[0];
+    const int first = q0 >= 0 ? 0 : (-q0 + QS - 1) / QS;
+    const int last = q0 >= np ? 0 : (np - q0 + QS - 1) / QS;
+    it_lo = __builtin_amdgcn_readlane(first, 63);
+    it_hi = __builtin_amdgcn_readfirstlane(last);
+  }
   if (tid < ACTIVE) {
     float4* o = out4 + tid;
     const int n_iter = (plan->n_sc - sc_lane + SC_STEP - 1) / SC_STEP;
-#pragma unroll 2
-    for (int it = 0; it < n_iter; ++it) {
+    auto body = [&](auto branchy) __attribute__((always_inline)) {
+      constexpr bool BR = decltype(branchy)::value;
       float2 y[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -601,7 +621,12 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
           lo = lo < 0 ? 0 : lo;                                       // at/before the first pilot: hold (T:315,320)
           if (!valid) lo = hi = 0;
           const float2 u = (CE_ABLATE & 64) ? make_float2(1.f, 2.f) : Pe[e][lo], v = (CE_ABLATE & 64) ? u : Pe[e][hi];  // 64: timing experiment, no LDS reads in the writer
-          y[e] = valid ? make_float2(u.x + al[e] * (v.x - u.x), u.y + al[e] * (v.y - u.y)) : make_float2(0.f, 0.f);
+          if constexpr (BR) {
+            y[e] = valid ? make_float2(u.x + al[e] * (v.x - u.x), u.y + al[e] * (v.y - u.y)) : make_float2(0.f, 0.f);
+          } else {
+            const float2 w = make_float2(u.x + al[e] * (v.x - u.x), u.y + al[e] * (v.y - u.y));
+            y[e] = make_float2(__builtin_unpredictable(valid) ? w.x : 0.f, __builtin_unpredictable(valid) ? w.y : 0.f);
+          }
           q[e] += QS;
           ro[e] += dro[e];
         }
@@ -609,6 +634,19 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
       const float2 ya = cmul(y[0], rsel[0]), yb = cmul(y[1], rsel[1]);
       store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
       o += ACTIVE;
+    };
+    if constexpr (NH == 1 && WRU > 0) {
+      const int lo_it = it_lo < n_iter ? it_lo : n_iter, hi_it = it_hi < n_iter ? (it_hi > lo_it ? it_hi : lo_it) : n_iter;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int it = 0; it < lo_it; ++it) { store_f4(o, z4); o += ACTIVE; }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { q[e] += lo_it * QS; ro[e] += lo_it * dro[e]; }
+#pragma unroll WRU
+      for (int it = lo_it; it < hi_it; ++it) body(std::false_type{});
+      for (int it = hi_it; it < n_iter; ++it) { store_f4(o, z4); o += ACTIVE; }
+    } else {
+#pragma unroll 2
+      for (int it = 0; it < n_iter; ++it) body(std::true_type{});
     }
   }
 }
@@ -1619,7 +1657,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         }
       }
     } else if (direct_ok<SC_STEP>() && lp->interp != CE_INTERP_CNN) {
-      if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);
+      if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH, (ce_min_waves(NH, ND, KPT, FEAT, L) >= 5 ? 2 : ce_min_waves(NH, ND, KPT, FEAT, L) == 2 ? 0 : CE_WR_UNROLL)>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);  // (the 96-VGPR tiers have no room for four iterations' operands; 0 = per-element branches: measured 2-4 % faster where only two workgroups share a CU)
     } else {
       const float2* HA = scratch + ((hsel[0] * L + lsel[0]) << ch_log2);
       const float2* HB = scratch + ((hsel[1] * L + lsel[1]) << ch_log2);
