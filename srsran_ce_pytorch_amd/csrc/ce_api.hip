@@ -286,13 +286,21 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     {
       H.ta_inv_off = h * CE_FFT_SIZE;
       unsigned seen = 0;
+      int pos_min = CE_FFT_SIZE, pos_max = 0;
       for (int k = 0; k < n_re; ++k) {
         const int pos = re_idx[H.re_off[n_cdm - 1] + k];
         ta_inv[(size_t)h * CE_FFT_SIZE + pos] = (uint16_t)k;
         seen |= 1u << (pos & 15);
+        pos_min = std::min(pos_min, pos);
+        pos_max = std::max(pos_max, pos);
       }
       for (int r = 0; r < 16; ++r)
         if (seen >> r & 1) { H.ta_res_packed |= (uint64_t)r << (4 * H.ta_nres); H.ta_res[H.ta_nres++] = r; }
+      // Narrow bands: |X[k]| does not change when the band is moved down by a multiple of 16 subcarriers (a unit phase per
+      // bin, the residues stay), and a band that then ends below subcarrier 256 / 512 has one / two non-zero inputs per
+      // 16-point transform of the first radix-16 pass, which collapses to a twiddle multiply (ce_estimate_kernel.h).
+      const int shift = pos_min & ~15, nb = (pos_max - shift) / 256 + 1;
+      H.ta_win = (nb <= 2 && !getenv("CE_TA_FULL")) ? (uint32_t)shift | ((uint32_t)nb << 16) : 0u;  // env: A/B knob
     }
     // nSamples = nSyms + sum(CPDs(i0+1 .. i1)), CPDs = cp_ms * (scs/1000) (T:395-426, called with scs/1000 at T:599)
     if (H.has_cfo) {

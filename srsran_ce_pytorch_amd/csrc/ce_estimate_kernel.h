@@ -899,40 +899,55 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         const unsigned idx = inv[n];
         return idx == 0xFFFFu ? -1 : (int)idx;
       };
-      // arg-max with first-index tie break on each side: key = (power bits, ~index); adds the hop's seconds to tot_ta
-      auto arg_max = [&](int h, float pw0, float pw1) {
-        unsigned long long kh = 0ull, kt = 0ull;
-        auto offer = [&](int b, float pw) {
-          if (b < NB) {
-            const int idx = b < CE_TA_HALF ? b : b - CE_TA_HALF;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(pw) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
-            if (b < CE_TA_HALF) kh = key > kh ? key : kh;
-            else kt = key > kt ? key : kt;
-          }
-        };
-        offer(b0, pw0);
-        offer(b1, pw1);
-        kh = wave_max_u64(kh);
-        kt = wave_max_u64(kt);
-        unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 48);  // own slot
+      // arg-max with first-index tie break on each side: key = (power bits, ~index); adds the hops' seconds to tot_ta.
+      // NHP hops at once (their keys reduced side by side: one barrier, and the independent DPP chains overlap).
+      auto arg_max = [&](auto nhp, int h, const float (&pw0)[2], const float (&pw1)[2]) {
+        constexpr int NHP = decltype(nhp)::value;
+        unsigned long long kh[NHP], kt[NHP];
+#pragma unroll
+        for (int j = 0; j < NHP; ++j) {
+          kh[j] = kt[j] = 0ull;
+          auto offer = [&](int b, float pw) {
+            if (b < NB) {
+              const int idx = b < CE_TA_HALF ? b : b - CE_TA_HALF;
+              const unsigned long long key = ((unsigned long long)__float_as_uint(pw) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
+              if (b < CE_TA_HALF) kh[j] = key > kh[j] ? key : kh[j];
+              else kt[j] = key > kt[j] ? key : kt[j];
+            }
+          };
+          offer(b0, pw0[j]);
+          offer(b1, pw1[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NHP; ++j) {
+          kh[j] = wave_max_u64(kh[j]);
+          kt[j] = wave_max_u64(kt[j]);
+        }
+        unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 32);  // own slot: [hop][wave][2], 16 entries
         if ((tid & 63) == 0) {
-          ared[(tid >> 6) * 2] = kh;
-          ared[(tid >> 6) * 2 + 1] = kt;
+#pragma unroll
+          for (int j = 0; j < NHP; ++j) {
+            ared[(j * NW + (tid >> 6)) * 2] = kh[j];
+            ared[(j * NW + (tid >> 6)) * 2 + 1] = kt[j];
+          }
         }
         __syncthreads();
         if (tid == 0) {
-          unsigned long long mh = 0ull, mt = 0ull;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            mh = ared[2 * w] > mh ? ared[2 * w] : mh;
-            mt = ared[2 * w + 1] > mt ? ared[2 * w + 1] : mt;
+          for (int j = 0; j < NHP; ++j) {
+            unsigned long long mh = 0ull, mt = 0ull;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+              mh = ared[(j * NW + w) * 2] > mh ? ared[(j * NW + w) * 2] : mh;
+              mt = ared[(j * NW + w) * 2 + 1] > mt ? ared[(j * NW + w) * 2 + 1] : mt;
+            }
+            const float vd = __uint_as_float((unsigned)(mh >> 32)), va = __uint_as_float((unsigned)(mt >> 32));
+            const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
+            const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
+            const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
+            tot_ta += (double)i_max / (double)CE_FFT_SIZE / lp->scs;  // T:698, the reference's two float64 divisions
+            if (a.stage_s) a.stage_s[(item * NH + h + j) * 2 + 1] = (double)i_max;
           }
-          const float vd = __uint_as_float((unsigned)(mh >> 32)), va = __uint_as_float((unsigned)(mt >> 32));
-          const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
-          const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
-          const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
-          tot_ta += (double)i_max / (double)CE_FFT_SIZE / lp->scs;  // T:698, the reference's two float64 divisions
-          if (a.stage_s) a.stage_s[(item * NH + h) * 2 + 1] = (double)i_max;
         }
       };
       float pw0 = 0.f, pw1 = 0.f;
@@ -943,17 +958,30 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         const bool unit = ri < nres && l < L;
         if (unit) {  // pass 1: DFT16 over b of x[r + 16 a + 256 b], times W256^(a c)
           const int r = (int)((res_packed >> (4 * ri)) & 15u);
-          float2 v[16];
-#pragma unroll
-          for (int b = 0; b < 16; ++b) {
-            const int idx = pilot_at(r + 16 * a4 + 256 * b);
-            v[b] = idx >= 0 ? Pl[idx] : make_float2(0.f, 0.f);
-          }
-          idft16(v);
           float2* blk = scr + ri * TA_ROW;
-          blk[ta_at<TA_LATE>(0, a4)] = v[0];
+          // (not in the 2-4-layer x 2-hop kernels: the stage sits inside their hop loop and a second form of it costs 10 more spilled registers)
+          const unsigned win = (L >= 2 && NH == 2) ? 0u : lh.ta_win;
+          if (win) {
+            // narrow band, moved down by `shift` subcarriers (plan): only b = 0 (and 1) carry pilots, so the 16-point
+            // transform over b is x0 + x1 W16^c -- one or two LDS reads and 16 multiplies instead of 16 reads + a DFT16
+            const int n0 = (int)(win & 0xFFFFu) + r + 16 * a4;
+            const int i0 = pilot_at(n0), i1 = (win >> 16) == 2u ? pilot_at(n0 + 256) : -1;
+            const float2 x0 = i0 >= 0 ? Pl[i0] : make_float2(0.f, 0.f), x1 = i1 >= 0 ? Pl[i1] : make_float2(0.f, 0.f);
+            blk[ta_at<TA_LATE>(0, a4)] = cadd(x0, x1);
 #pragma unroll
-          for (int c = 1; c < 16; ++c) blk[ta_at<TA_LATE>(c, a4)] = cmul(v[c], tw256[a4 * c]);
+            for (int c = 1; c < 16; ++c) blk[ta_at<TA_LATE>(c, a4)] = cmul(cadd(x0, cmul(x1, tw256[16 * c])), tw256[a4 * c]);
+          } else {
+            float2 v[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+              const int idx = pilot_at(r + 16 * a4 + 256 * b);
+              v[b] = idx >= 0 ? Pl[idx] : make_float2(0.f, 0.f);
+            }
+            idft16(v);
+            blk[ta_at<TA_LATE>(0, a4)] = v[0];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) blk[ta_at<TA_LATE>(c, a4)] = cmul(v[c], tw256[a4 * c]);
+          }
         }
         __syncthreads();
         if (unit) {  // pass 2 (in place): DFT16 over a for fixed c = a4 -> Y_r[c + 16 d] at element (c, d)
@@ -980,17 +1008,19 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         STAMP(15);
       }
       if (!hpar) {
-        arg_max(h0, pw0, pw1);
+        const float p0[2] = {pw0, 0.f}, p1[2] = {pw1, 0.f};
+        arg_max(std::integral_constant<int, 1>{}, h0, p0, p1);
       } else {
-#pragma unroll 1
-        for (int s2 = 0; s2 < 2; ++s2) {  // one layer: each hop's bins straight from its blocks
+        // one layer: each hop's bins straight from its blocks, then both hops' arg-max in one round
+        float p0[2], p1[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
           const CeDevHop& bh = lp->hop[h0 + s2];
           const float2* blocks = scratch + s2 * (8 * TA_ROW);
-          const float q0 = b0 < NB ? bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0, blocks, bh.ta_nres, bh.ta_res_packed) : 0.f;
-          const float q1 = b1 < NB ? bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1, blocks, bh.ta_nres, bh.ta_res_packed) : 0.f;
-          arg_max(h0 + s2, q0, q1);
-          __syncthreads();  // the next hop's arg-max reuses the key slots
+          p0[s2] = b0 < NB ? bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0, blocks, bh.ta_nres, bh.ta_res_packed) : 0.f;
+          p1[s2] = b1 < NB ? bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1, blocks, bh.ta_nres, bh.ta_res_packed) : 0.f;
         }
+        arg_max(std::integral_constant<int, 2>{}, h0, p0, p1);
       }
     }
   };

@@ -119,7 +119,7 @@ struct CeDevHop {
   uint64_t ord_packed;                // last CDM group: 4 bits per RE r: pilot ordinal inside the PRB, 15 = not a pilot
   uint64_t ta_res_packed;             // 4 bits per entry of ta_res
   uint32_t mask12;                    // DMRSREmask columns: bits 0-11 CDM group 0, bits 16-27 CDM group 1
-  uint32_t pad1;
+  uint32_t ta_win;                    // narrow band: (blocks of 256 subcarriers the shifted band spans, 1 or 2) << 16 | shift (multiple of 16); 0: full first pass
 };
 
 struct alignas(16) CeDevPlan {
@@ -181,7 +181,7 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
   l.off_red = o;      o += (CE_THREADS / 64) * 16 * 8;           // 16 doubles per wave
   l.off_rot = o;      o += (1 + 2 * CE_MAX_HOPS) * 16 * 8;       // final, per-hop -/+ phasors, 16 float2 each
   l.off_tab = o;      o += CE_MAX_HOPS * CE_MAX_CDM * 12 * 8;    // {alpha, r_ord} pairs
-  l.off_misc = o;     o += 56 * 8;                               // doubles: cfo_hop[2], ..., TA arg-max keys[8] at [48]
+  l.off_misc = o;     o += 56 * 8;                               // doubles: cfo_hop[2], ..., TA arg-max keys [2 hops][4 waves][2] at [32]
   l.off_tw = o;       o += (256 + 16) * 8;                       // W256^j, W4096^i for the TA transform
   l.off_rcz = o;                                                 // (the RC taps are read from the LDS plan copy)
   l.off_plan = o;     o += (int)((sizeof(CeDevPlan) + 15) & ~15); // LDS copy of the plan (no scalar loads from global later)
