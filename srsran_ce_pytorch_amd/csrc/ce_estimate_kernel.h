@@ -899,52 +899,43 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         const unsigned idx = inv[n];
         return idx == 0xFFFFu ? -1 : (int)idx;
       };
-      // arg-max with first-index tie break on each side: key = (power bits, ~index); adds the hops' seconds to tot_ta.
+      // arg-max: T:683-696 takes the first maximum of the delay side (bins 0..143), the first maximum of the advance side
+      // (bins 3952..4095) and prefers the delay side when the two are equal.  One key orders all 288 bins that way --
+      // (power bits, delay side before advance side, lower index first) -- so one wave reduction per hop finds the winner.
       // NHP hops at once (their keys reduced side by side: one barrier, and the independent DPP chains overlap).
+      // Adds the hops' seconds to tot_ta.
       auto arg_max = [&](auto nhp, int h, const float (&pw0)[2], const float (&pw1)[2]) {
         constexpr int NHP = decltype(nhp)::value;
-        unsigned long long kh[NHP], kt[NHP];
+        unsigned long long key[NHP];
 #pragma unroll
         for (int j = 0; j < NHP; ++j) {
-          kh[j] = kt[j] = 0ull;
+          key[j] = 0ull;
           auto offer = [&](int b, float pw) {
             if (b < NB) {
-              const int idx = b < CE_TA_HALF ? b : b - CE_TA_HALF;
-              const unsigned long long key = ((unsigned long long)__float_as_uint(pw) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
-              if (b < CE_TA_HALF) kh[j] = key > kh[j] ? key : kh[j];
-              else kt[j] = key > kt[j] ? key : kt[j];
+              const unsigned low = b < CE_TA_HALF ? 0xFFFFFFFFu - (unsigned)b : 0x7FFFFFFFu - (unsigned)(b - CE_TA_HALF);
+              const unsigned long long k = ((unsigned long long)__float_as_uint(pw) << 32) | low;
+              key[j] = k > key[j] ? k : key[j];
             }
           };
           offer(b0, pw0[j]);
           offer(b1, pw1[j]);
         }
 #pragma unroll
-        for (int j = 0; j < NHP; ++j) {
-          kh[j] = wave_max_u64(kh[j]);
-          kt[j] = wave_max_u64(kt[j]);
-        }
-        unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 32);  // own slot: [hop][wave][2], 16 entries
+        for (int j = 0; j < NHP; ++j) key[j] = wave_max_u64(key[j]);
+        unsigned long long* ared = reinterpret_cast<unsigned long long*>(misc + 32);  // own slot: [hop][wave]
         if ((tid & 63) == 0) {
 #pragma unroll
-          for (int j = 0; j < NHP; ++j) {
-            ared[(j * NW + (tid >> 6)) * 2] = kh[j];
-            ared[(j * NW + (tid >> 6)) * 2 + 1] = kt[j];
-          }
+          for (int j = 0; j < NHP; ++j) ared[j * NW + (tid >> 6)] = key[j];
         }
         __syncthreads();
         if (tid == 0) {
 #pragma unroll
           for (int j = 0; j < NHP; ++j) {
-            unsigned long long mh = 0ull, mt = 0ull;
+            unsigned long long m = 0ull;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-              mh = ared[(j * NW + w) * 2] > mh ? ared[(j * NW + w) * 2] : mh;
-              mt = ared[(j * NW + w) * 2 + 1] > mt ? ared[(j * NW + w) * 2 + 1] : mt;
-            }
-            const float vd = __uint_as_float((unsigned)(mh >> 32)), va = __uint_as_float((unsigned)(mt >> 32));
-            const int i_delay = (int)(0xFFFFFFFFu - (unsigned)(mh & 0xFFFFFFFFull));
-            const int i_adv = (int)(0xFFFFFFFFu - (unsigned)(mt & 0xFFFFFFFFull));
-            const int i_max = (vd >= va) ? i_delay : -(CE_TA_HALF - i_adv);
+            for (int w = 0; w < NW; ++w) m = ared[j * NW + w] > m ? ared[j * NW + w] : m;
+            const unsigned low = (unsigned)(m & 0xFFFFFFFFull);
+            const int i_max = (low & 0x80000000u) ? (int)(0xFFFFFFFFu - low) : -(CE_TA_HALF - (int)(0x7FFFFFFFu - low));
             tot_ta += (double)i_max / (double)CE_FFT_SIZE / lp->scs;  // T:698, the reference's two float64 divisions
             if (a.stage_s) a.stage_s[(item * NH + h + j) * 2 + 1] = (double)i_max;
           }
