@@ -8,7 +8,12 @@
 //   B = activations [K 32][16 columns of one subcarrier row], K = 2 taps x 16 input channels:
 //       lane l: column l&15, tap 2m + (l>>5), channels 8((l>>4)&1) .. +7  -> one ds_read_b128 per MFMA
 //   D lane l: column l&15, c_out 4(l>>4)+i -> one ds_write_b64 per tile.
-// 9 taps = 4.5 K-steps -> 5 MFMAs per row of layer 2; tap 9 has zero weights and re-reads tap 8's address.
+// Layer 2 (16 -> 16 channels, the bulk of the work): a wave owns a BAND of consecutive output rows and pairs the taps so
+// that a B fragment belongs to ONE input row (or two adjacent ones) and serves every output row that touches it:
+//   A_i = (row i, dx=-1 | row i, dx=0)  used by output rows i, i-1, i-2 (as ky = 0, 1, 2)
+//   C_i = (row i, dx=+1 | row i+1, dx=+1)  used by output rows i (ky = 0, 1) and i-2 (ky = 2; upper half: zero weights)
+// 5 MFMAs per output row as before, but 2 LDS fragment reads instead of 5 (round 1: one read per MFMA = the LDS
+// array's full rate, the kernel's bound).
 // Layer 3 has only 2 output channels, so its 16 MFMA rows hold (4 subcarrier rows x re|im, 8 rows used) and K runs over
 // the 6 input rows x 3 symbol taps x 16 channels that a block of 4 output rows sees (9 K-steps; the weight matrix is
 // banded: a row's 3 x 3 taps, zeros elsewhere) -- 9 MFMAs and 9 LDS reads per 4 rows instead of 20.
@@ -16,6 +21,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "ce_denoise.h"
@@ -41,6 +47,12 @@ namespace {
 #ifndef DN_MIN_WAVES
 #define DN_MIN_WAVES 3   // workgroups per CU the register allocator leaves room for (41 KB of LDS allow 3)
 #endif
+#ifndef DN_TWO_BODIES
+#define DN_TWO_BODIES 0   // 1: a second copy of the strip body without row tests for interior strips
+#endif
+#ifndef DN_L3_BUF
+#define DN_L3_BUF 2   // layer 3: fragment sets in flight (2 = the next block's requested before this block's MFMA chain: 36 more VGPRs; 4.53 -> 4.40 ms)
+#endif
 #ifndef DN_T_ROWS
 #define DN_T_ROWS 32
 #endif
@@ -49,7 +61,7 @@ constexpr int DN_NB3 = DN_T / 16;         // layer-3 blocks per wave
 static_assert(DN_T % 16 == 0, "strip height");
 constexpr int DN_NT = 256, DN_COLS = 16, DN_C = CE_DN_CHANNELS;
 constexpr int X0_PIX = (DN_T + 6) * DN_COLS + 2;  // + one pad pixel in front and behind
-constexpr int X1_PIX = (DN_T + 4) * DN_COLS + 2;
+constexpr int X1_PIX = (DN_T + 5) * DN_COLS + 2;  // + one row that only zero-weight lanes of the last C fragment read
 constexpr int X2_PIX = (DN_T + 2) * DN_COLS + 2;
 
 __device__ __forceinline__ int tap_off(int tap) {  // pixel offset of tap t = 3 (dy+1) + (dx+1) in the [row][16] image
@@ -63,11 +75,24 @@ constexpr int ROW_BYTES0 = DN_COLS * 4;          // one image row of x0 (fp16 re
 // fp16 + ReLU of one D fragment (c_out 4g .. 4g+3 of one pixel): round first, then a packed max -- rounding to
 // nearest is monotonic and keeps the sign, so this equals fp16(ReLU(x)); 2 converts + 2 packed max instead of 8 + 2
 typedef _Float16 half2x __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ half4 relu_h4(f32x4 acc) {
+__device__ __forceinline__ float2 masked(float2 v, bool ok) {  // v, or +0 where !ok, without a branch
+  const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+  return make_float2(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m));
+}
+// `keep` = all ones, or 0 on the lanes of the two padding columns: their pixels must stay zero, and an AND is cheaper than
+// an exec-masked store (s_and_saveexec + branch + restore around every tile's ds_write)
+__device__ __forceinline__ half4 relu_h4(f32x4 acc, unsigned keep) {
   half2x lo = half2x{(_Float16)acc[0], (_Float16)acc[1]}, hi = half2x{(_Float16)acc[2], (_Float16)acc[3]};
   const half2x z = half2x{0, 0};
   lo = __builtin_elementwise_max(lo, z);
   hi = __builtin_elementwise_max(hi, z);
+  unsigned ulo, uhi;
+  __builtin_memcpy(&ulo, &lo, 4);
+  __builtin_memcpy(&uhi, &hi, 4);
+  ulo &= keep;
+  uhi &= keep;
+  __builtin_memcpy(&lo, &ulo, 4);
+  __builtin_memcpy(&hi, &uhi, 4);
   return half4{lo[0], lo[1], hi[0], hi[1]};
 }
 
@@ -107,6 +132,7 @@ __global__ __launch_bounds__(DN_NT, DN_MIN_WAVES) void ce_denoise_kernel(float2*
 
   // ---- per-lane constants
   const bool col_ok = n >= 1 && n <= CE_DN_SYMBOLS;
+  const unsigned keep = col_ok ? 0xFFFFFFFFu : 0u;
   // layer 1 reads: taps 4g .. 4g+3 of x0 at image row wave + 1 (+ 4k rows per tile)
   int rd0[4];
 #pragma unroll
@@ -114,16 +140,19 @@ __global__ __launch_bounds__(DN_NT, DN_MIN_WAVES) void ce_denoise_kernel(float2*
     const int tap = 4 * g + q;
     rd0[q] = (1 + (wave + 1) * DN_COLS + n + tap_off(tap < 9 ? tap : 4)) * 4;
   }
-  // 16-channel layers: K-step m reads tap 2m + (g >> 1), channels 8 (g & 1) .. +7, at image row wave + 1
   // The two 16-byte channel halves of pixel p are stored swapped when bit 2 of p is set: the b128 fragment reads stay
   // conflict-free and the D-fragment ds_write_b64 (16 lanes, 32-byte stride) drops from a 4-way to a 2-way bank conflict.
-  // Tiles advance by 64 pixels, so the swap is a per-lane constant.
-  int rd[5];
-#pragma unroll
-  for (int m = 0; m < 5; ++m) {
-    const int tap = 2 * m + (g >> 1);
-    const int pix = 1 + (wave + 1) * DN_COLS + n + tap_off(tap < 9 ? tap : 8);
-    rd[m] = pix * (DN_C * 2) + (((g & 1) ^ ((pix >> 2) & 1)) * 16);
+  // Rows advance by 16 pixels, so the swap is a per-lane constant.
+  // layer 2: the wave's band of x2 image rows starts at row a2; fragment A of x1 row a2: pixel column n - 1 (lanes g < 2)
+  // or n (g >= 2); fragment C: column n + 1 of row a2 (g < 2) or a2 + 1 (g >= 2); channels 8 (g & 1) .. +7
+  constexpr int R2 = (DN_T + 2 + 3) / 4;   // output rows per wave; the last wave's band is moved up so that it ends with the image
+  const int a2 = wave * R2 < DN_T + 2 - R2 ? wave * R2 : DN_T + 2 - R2;  // (it recomputes two of its neighbour's rows: same values, no branches in the loop)
+  int rdA, rdC, wr2;
+  {
+    const int pa = 1 + a2 * DN_COLS + n - 1 + (g >> 1), pc = 1 + (a2 + (g >> 1)) * DN_COLS + n + 1, pw = 1 + a2 * DN_COLS + n;
+    rdA = pa * (DN_C * 2) + (((g & 1) ^ ((pa >> 2) & 1)) * 16);
+    rdC = pc * (DN_C * 2) + (((g & 1) ^ ((pc >> 2) & 1)) * 16);
+    wr2 = pw * (DN_C * 2) + ((((g >> 1) & 1) ^ ((pw >> 2) & 1)) * 16) + (g & 1) * 8;  // D fragment of x2 row a2: channels 4g .. 4g+3
   }
   const int wpix = 1 + wave * DN_COLS + n;  // D fragment of image row wave: channels 4g .. 4g+3
   const int wr = wpix * (DN_C * 2) + ((((g >> 1) & 1) ^ ((wpix >> 2) & 1)) * 16) + (g & 1) * 8;
@@ -157,9 +186,16 @@ __global__ __launch_bounds__(DN_NT, DN_MIN_WAVES) void ce_denoise_kernel(float2*
     const float2* sb = base + (int64_t)r0 * CE_DN_SYMBOLS * L;
 #pragma unroll
     for (int k = 0; k < ST_N; ++k) {
-      st[k] = make_float2(0.f, 0.f);
-      if (!(DN_ABLATE & 2) && st_ok[k] && (unsigned)(r0 + st_row[k]) < (unsigned)n_sc) st[k] = sb[st_off[k]];
+      // unconditional load from an in-range address + AND with the lane's validity mask: left as `if (ok) load`, every
+      // load sat inside four nested exec-mask regions with the zero fill repeated in each (25 instructions per load)
+      const bool ok = st_ok[k] && (unsigned)(r0 + st_row[k]) < (unsigned)n_sc;
+      st[k] = masked((DN_ABLATE & 2) ? make_float2(0.f, 0.f) : sb[ok ? st_off[k] : 0], ok);
     }
+  };
+  auto stage_load_in = [&](int r0) {  // the same when every row is known to be inside the grid
+    const float2* sb = base + (int64_t)r0 * CE_DN_SYMBOLS * L;
+#pragma unroll
+    for (int k = 0; k < ST_N; ++k) st[k] = masked((DN_ABLATE & 2) ? make_float2(0.f, 0.f) : sb[st_ok[k] ? st_off[k] : 0], st_ok[k]);
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
@@ -173,26 +209,36 @@ __global__ __launch_bounds__(DN_NT, DN_MIN_WAVES) void ce_denoise_kernel(float2*
   stage_store(0);
   __syncthreads();
   const int n_strips = (n_sc + DN_T - 1) / DN_T;
-#pragma unroll 1
-  for (int s = 0; s < n_strips; ++s) {
+  // EDGE strips (rows above / below the grid in reach: the first and the last one or two) test every tile's row; interior
+  // strips -- all but 2-3 of a 273-PRB plane's 103 -- carry no row tests at all (they were a third of the loop's instructions)
+  auto strip = [&](auto edge_tag, int s) __attribute__((always_inline)) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
     const int r0 = s * DN_T, buf = s & 1;
     float2* sb = base + (int64_t)r0 * CE_DN_SYMBOLS * L;
     // The next strip's input rows overlap this strip's output rows: request them (and this strip's float32 residuals)
     // now, before layer 3 overwrites them; they are consumed after layer 1 / in layer 3.
-    if (s + 1 < n_strips) stage_load(r0 + DN_T);
+    if (s + 1 < n_strips) {
+      if (!EDGE && r0 + 2 * DN_T + 3 <= n_sc) stage_load_in(r0 + DN_T); else stage_load(r0 + DN_T);  // rows r0+T-3 .. r0+2T+2
+    }
     float2 hres[DN_NB3][2];  // [block][row 2g + e]: float32 residuals of this lane's outputs
 #pragma unroll
     for (int b = 0; b < DN_NB3; ++b)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        hres[b][e] = make_float2(0.f, 0.f);
-        if (!(DN_ABLATE & 2) && h_lane && r0 + h_row + 16 * b + e < n_sc) hres[b][e] = sb[h_off + (16 * b + e) * CE_DN_SYMBOLS * L];
+        const bool ok = h_lane && (!EDGE || r0 + h_row + 16 * b + e < n_sc);
+        hres[b][e] = masked((DN_ABLATE & 2) ? make_float2(0.f, 0.f) : sb[ok ? h_off + (16 * b + e) * CE_DN_SYMBOLS * L : 0], ok);
       }
     // ---- layer 1: x0 -> x1 image rows 0 .. T+3 (image row t <-> grid row r0-2+t); K = (tap, re | im)
     {
       const char* xin = reinterpret_cast<const char*>(&x0[buf][0]);
       char* xout = reinterpret_cast<char*>(x1);
       constexpr int NK1 = (DN_T + 4) / 4;
+      auto finish1 = [&](f32x4 acc, int k) __attribute__((always_inline)) {
+        const int row = r0 - 2 + wave + 4 * k;  // wave-uniform: outside the grid the next layer must see zero padding
+        const unsigned rowkeep = (!EDGE || (row >= 0 && row < n_sc)) ? keep : 0u;   // scalar select, one AND: no branch, no zero fill
+        *reinterpret_cast<half4*>(xout + wr + k * 4 * ROW_BYTES16) = relu_h4(acc, rowkeep);
+      };
+      f32x4 accp = b1;
       half2v px[2][4];  // tile k+1's pixels are requested before tile k's MFMA (same fence as in layer 2)
 #pragma unroll
       for (int q = 0; q < 4; ++q) px[0][q] = *reinterpret_cast<const half2v*>(xin + rd0[q]);
@@ -210,76 +256,91 @@ __global__ __launch_bounds__(DN_NT, DN_MIN_WAVES) void ce_denoise_kernel(float2*
           b[2 * q + 1] = px[k & 1][q][1];
         }
         const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b, b1, 0, 0, 0);
-        const int row = r0 - 2 + wave + 4 * k;  // wave-uniform: outside the grid the next layer must see zero padding
-        half4 o = half4{0, 0, 0, 0};
-        if (row >= 0 && row < n_sc) o = relu_h4(acc);
-        if (col_ok) *reinterpret_cast<half4*>(xout + wr + k * 4 * ROW_BYTES16) = o;
+        if (k > 0) finish1(accp, k - 1);  // the previous tile's epilogue, behind this tile's MFMA (see layer 2)
+        accp = acc;
       }
+      finish1(accp, NK1 - 1);
     }
     __syncthreads();
     if (s + 1 < n_strips) stage_store(buf ^ 1);  // x0[buf ^ 1] was last read by layer 1 of the previous strip
-    // ---- layer 2: x1 -> x2 image rows 0 .. T+1 (image row t <-> grid row r0-1+t).  The five B fragments of tile k+1
-    // are requested before tile k's MFMA chain (the compiler fence keeps the scheduler from sinking them back next to
-    // their uses, where every MFMA would wait for its own LDS read).  T+2 = 34 rows: 8 tiles for every wave, a ninth
-    // for waves 0 and 1.
+    // ---- layer 2: x1 -> x2 image rows 0 .. T+1 (image row t <-> grid row r0-1+t; x2 row t sees x1 rows t, t+1, t+2).
+    // The wave walks its band row by row; the fragments of input row t+3 are requested before row t's MFMA chain (the
+    // compiler fence keeps the scheduler from sinking them back next to their uses).
     {
       const char* xin = reinterpret_cast<const char*>(x1);
       char* xout = reinterpret_cast<char*>(x2);
-      auto finish = [&](f32x4 acc, int k) {
-        const int row = r0 - 1 + wave + 4 * k;
-        half4 o = half4{0, 0, 0, 0};
-        if (row >= 0 && row < n_sc) o = relu_h4(acc);
-        if (col_ok) *reinterpret_cast<half4*>(xout + wr + k * 4 * ROW_BYTES16) = o;
+      half8 fa[R2 + 2], fc[R2 + 2];
+      auto fetch = [&](int i) __attribute__((always_inline)) {  // fragments of x1 row a2 + i
+        fa[i] = *reinterpret_cast<const half8*>(xin + rdA + i * ROW_BYTES16);
+        fc[i] = *reinterpret_cast<const half8*>(xin + rdC + i * ROW_BYTES16);
       };
-      constexpr int NK = DN_T / 4;
-      half8 fr[2][5];
+      fetch(0);
+      fetch(1);
+      fetch(2);
+      // Row j's conversion + ReLU + store is issued AFTER row j+1's MFMA chain: it then runs in the vector-issue slots the
+      // chain leaves free instead of stalling the wave on the chain's result before the next chain may start.
+      auto finish2 = [&](f32x4 acc, int j) __attribute__((always_inline)) {
+        const int row = r0 - 1 + a2 + j;  // wave-uniform: outside the grid the next layer must see zero padding
+        const unsigned rowkeep = (!EDGE || (row >= 0 && row < n_sc)) ? keep : 0u;
+        *reinterpret_cast<half4*>(xout + wr2 + j * ROW_BYTES16) = relu_h4(acc, rowkeep);
+      };
+      f32x4 accp = b2;
 #pragma unroll
-      for (int m = 0; m < 5; ++m) fr[0][m] = *reinterpret_cast<const half8*>(xin + rd[m]);
-#pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        if (k + 1 < NK) {
-#pragma unroll
-          for (int m = 0; m < 5; ++m) fr[(k + 1) & 1][m] = *reinterpret_cast<const half8*>(xin + rd[m] + (k + 1) * 4 * ROW_BYTES16);
-        }
+      for (int j = 0; j < R2; ++j) {
+        if (j + 3 < R2 + 2) fetch(j + 3);  // (needed by row j + 1 on)
         asm volatile("" ::: "memory");
         f32x4 acc = b2;
-#pragma unroll
-        for (int m = 0; m < 5; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[m], fr[k & 1][m], acc, 0, 0, 0);
-        finish(acc, k);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[0], fa[j], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[1], fa[j + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[2], fa[j + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[3], fc[j], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[4], fc[j + 2], acc, 0, 0, 0);
+        if (j > 0) finish2(accp, j - 1);
+        accp = acc;
       }
-      if (wave < 2) {
-        f32x4 acc = b2;
-#pragma unroll
-        for (int m = 0; m < 5; ++m)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[m], *reinterpret_cast<const half8*>(xin + rd[m] + NK * 4 * ROW_BYTES16), acc, 0, 0, 0);
-        finish(acc, NK);
-      }
+      finish2(accp, R2 - 1);
     }
     __syncthreads();
     // ---- layer 3 + residual: x2 -> grid rows r0 .. r0+T-1, T/16 blocks of 4 rows per wave (rows 4 wave + 16 b ..)
     {
       const char* xin = reinterpret_cast<const char*>(x2);
-      half8 fr[2][9];
+      auto finish3 = [&](f32x4 acc, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          if ((!(DN_ABLATE & 1) || acc[0] == 123.456f) && h_lane && (!EDGE || r0 + h_row + 16 * b + e < n_sc))
+            sb[h_off + (16 * b + e) * CE_DN_SYMBOLS * L] = make_float2(hres[b][e].x + acc[2 * e], hres[b][e].y + acc[2 * e + 1]);
+      };
+      f32x4 accp = b3;
+      half8 fr[DN_L3_BUF][9];
 #pragma unroll
       for (int j = 0; j < 9; ++j) fr[0][j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (j / 3) * ROW_BYTES16);
 #pragma unroll
       for (int b = 0; b < DN_NB3; ++b) {
-        if (b + 1 < DN_NB3) {
+        if (DN_L3_BUF == 2 && b + 1 < DN_NB3) {
 #pragma unroll
           for (int j = 0; j < 9; ++j) fr[(b + 1) & 1][j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (16 * (b + 1) + j / 3) * ROW_BYTES16);
+        }
+        if (DN_L3_BUF == 1 && b > 0) {
+#pragma unroll
+          for (int j = 0; j < 9; ++j) fr[0][j] = *reinterpret_cast<const half8*>(xin + rd3[j % 3] + (16 * b + j / 3) * ROW_BYTES16);
         }
         asm volatile("" ::: "memory");
         f32x4 acc = b3;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[j], fr[b & 1][j], acc, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-          if ((!(DN_ABLATE & 1) || acc[0] == 123.456f) && h_lane && r0 + h_row + 16 * b + e < n_sc)
-            sb[h_off + (16 * b + e) * CE_DN_SYMBOLS * L] = make_float2(hres[b][e].x + acc[2 * e], hres[b][e].y + acc[2 * e + 1]);
+        for (int j = 0; j < 9; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[j], fr[b & (DN_L3_BUF - 1)][j], acc, 0, 0, 0);
+        if (b > 0) finish3(accp, b - 1);
+        accp = acc;
       }
+      finish3(accp, DN_NB3 - 1);
     }
     // no barrier here: layer 1 of the next strip writes x1, which every wave finished reading before the barrier
     // above; x2 is rewritten only after the next strip's first barrier, i.e. after every wave left this loop
+  };
+#pragma unroll 1
+  for (int s = 0; s < n_strips; ++s) {
+    const int r0 = s * DN_T;
+    if (DN_TWO_BODIES && r0 >= 3 && r0 + DN_T + 3 <= n_sc) strip(std::false_type{}, s);
+    else strip(std::true_type{}, s);
   }
 }
 
@@ -299,11 +360,12 @@ extern "C" int ce_denoiser_create(int32_t device, const float* w1, const float* 
       const int k = 8 * g + j, tap = k >> 1, ci = k & 1;
       if (tap < 9) at(0, lane, j) = to_h(w1[(co * 2 + ci) * 9 + tap]);
     }
-    for (int m = 0; m < 5; ++m)
-      for (int j = 0; j < 8; ++j) {  // 16-channel layers: K-step m covers taps 2m, 2m+1; k = 16 (tap & 1) + c_in
-        const int tap = 2 * m + (g >> 1), ci = 8 * (g & 1) + j;
-        if (tap < 9) at(1 + m, lane, j) = to_h(w2[(co * 16 + ci) * 9 + tap]);
-      }
+    for (int j = 0; j < 8; ++j) {  // layer 2: k = 16 (g >> 1) + c_in; fragments A (ky = 0, 1, 2): taps (ky, dx=-1 | ky, dx=0);
+      const int ci = 8 * (g & 1) + j, up = g >> 1;   // C0: (ky=0, dx=+1 | ky=1, dx=+1); C1: (ky=2, dx=+1 | zero)
+      for (int ky = 0; ky < 3; ++ky) at(1 + ky, lane, j) = to_h(w2[(co * 16 + ci) * 9 + ky * 3 + up]);
+      at(4, lane, j) = to_h(w2[(co * 16 + ci) * 9 + up * 3 + 2]);
+      if (!up) at(5, lane, j) = to_h(w2[(co * 16 + ci) * 9 + 2 * 3 + 2]);
+    }
     // layer 3, banded over a block of 4 output rows: D row = 2 r + (re | im), r = 0..3 (rows 8..15 unused); K-step m,
     // lane group g: input row ri = m / 3 + 3 (g >> 1) of the block's 6, symbol tap dx = m % 3, channels 8 (g & 1) + j
     if (co < 8)
