@@ -121,6 +121,11 @@ RANDOM_CASES = [
     S.case_spec("rnd_4dmrs_2hop_120prb", 273, [S.hop_spec([0, 2, 4, 6], 5, 120, 0, 7), S.hop_spec([7, 9, 11, 13], 150, 120, 7, 7)], smoothing="none", seed=113),
     S.case_spec("rnd_3dmrs_2hop_200prb", 273, [S.hop_spec([0, 3, 6], 0, 200, 0, 7), S.hop_spec([7, 10, 13], 73, 200, 7, 7)], smoothing="mean", seed=114),
     S.case_spec("rnd_2hop_200prb", 273, [S.hop_spec([1, 5], 0, 200, 0, 7), S.hop_spec([8, 12], 73, 200, 7, 7)], seed=115),
+    # two hops whose DM-RS symbols do not fit registers: fetched once per hop and parked in the LDS (plan: pil_stash) --
+    # all of them (200 PRB x 2 symbols), some of them (3 symbols), and hops so wide that fewer fit next to both hops' P
+    S.case_spec("rnd_3dmrs_2hop_200prb_filter", 273, [S.hop_spec([0, 3, 6], 0, 200, 0, 7), S.hop_spec([7, 10, 13], 73, 200, 7, 7)], seed=116),
+    S.case_spec("rnd_2hop_fullband", 273, [S.hop_spec([1, 5], 0, 273, 0, 7), S.hop_spec([8, 12], 0, 273, 7, 7)], seed=117),
+    S.case_spec("rnd_2hop_250prb_3dmrs", 273, [S.hop_spec([0, 2, 5], 0, 250, 0, 7), S.hop_spec([8, 10, 13], 23, 250, 7, 7)], smoothing="none", seed=118),
     S.case_spec("rnd_3dmrs_2hop_40prb", 106, [S.hop_spec([0, 3, 6], 2, 40, 0, 7), S.hop_spec([7, 10, 13], 60, 40, 7, 7)], seed=109),
 ]
 
