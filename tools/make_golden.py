@@ -68,6 +68,11 @@ def golden_cases():
         (CS("hop2_136prb_273", 273, [H([1, 5], 0, 136, 0, 7), H([8, 12], 137, 136, 7, 7)], seed=33), "T", 1),
         (CS("dmrs4_20prb", 52, [H([2, 5, 8, 11], 7, 20)], seed=34), "T", 2),
         (CS("dmrs3_70prb_106", 106, [H([2, 7, 11], 30, 70)], scs=15e3, smoothing="mean", seed=35), "T", 1),
+        # two-hop tiers whose DM-RS symbols are fetched once per hop and parked in the LDS (all of them / two of three), and a
+        # narrow two-hop grid whose TA transform takes the collapsed first pass in both hops
+        (CS("hop2_200prb_273", 273, [H([1, 5], 0, 200, 0, 7), H([8, 12], 73, 200, 7, 7)], seed=36), "T", 1),
+        (CS("hop2_200prb_3dmrs_273", 273, [H([0, 3, 6], 0, 200, 0, 7), H([7, 10, 13], 73, 200, 7, 7)], seed=37), "T", 1),
+        (CS("hop2_12prb_1dmrs_52", 52, [H([2], 3, 12, 0, 7), H([9], 30, 12, 7, 7)], seed=38), "T", 2),
         (CS("cnn_3prb", 52, [H([2, 11], 7, 3)], seed=20), "C", 2),
         (CS("cnn_type2_3prb", 52, [H([2, 11], 7, 3, re_masks=[S.TYPE2_CDM0])], seed=21), "C", 2),
         (CS("cnn_type2_2hop", 52, [H([2], 3, 3, 0, 7, [S.TYPE2_CDM0]), H([9], 28, 3, 7, 7, [S.TYPE2_CDM0])], seed=23), "C", 1),
