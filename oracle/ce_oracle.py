@@ -362,9 +362,15 @@ def process_hop(hop: HopConfig, pilots: np.ndarray, smoothing: str, rg: np.ndarr
     i_max = i_delay if float(head[i_delay]) >= float(tail[i_adv]) else -(HALF_CP - (i_adv + 1) + 1)
     ta = float(i_max) / float(FFT_SIZE) / float(scs)
     if stages is not None:
-        side, i = (head, i_delay) if i_max >= 0 else (tail, i_adv)
-        stages.append(dict(p_ls=p_ls, p_smooth=p.copy(), cfo_hop=cfo_hop, ta_bin=i_max,
-                           ta_pw=[float(side[i - 1]) if i > 0 else -1.0, float(side[i]), float(side[i + 1]) if i + 1 < HALF_CP else -1.0]))
+        # power at the chosen bin and at its two neighbours among the examined bins; bins 4095 (the advance side's last)
+        # and 0 (the delay side's first) are neighbours too -- a peak between them is decided by the `>=` above
+        if i_max >= 0:
+            lo = float(head[i_delay - 1]) if i_delay > 0 else float(tail[HALF_CP - 1])
+            top, hi = float(head[i_delay]), float(head[i_delay + 1]) if i_delay + 1 < HALF_CP else -1.0
+        else:
+            lo = float(tail[i_adv - 1]) if i_adv > 0 else -1.0
+            top, hi = float(tail[i_adv]), float(tail[i_adv + 1]) if i_adv + 1 < HALF_CP else float(head[0])
+        stages.append(dict(p_ls=p_ls, p_smooth=p.copy(), cfo_hop=cfo_hop, ta_bin=i_max, ta_pw=[lo, top, hi]))
 
     # S9-S11: reconstruct the received pilots, fill the grid, residual + RSRP (T:700-730)
     est_rx = np.zeros_like(rx_pilots)

@@ -68,7 +68,9 @@ TA_TIE_RATIO = 1e-5
 def ta_tie_alternatives(fx, item):
     """TA values that differ from the reference's by ONE bin in ONE hop towards a neighbour whose power, in the
     reference's own transform, is within TA_TIE_RATIO of the winner's -- computed with the reference's arithmetic
-    (T:698, T:918-919) so the comparison stays exact."""
+    (T:698, T:918-919) so the comparison stays exact.  Neighbours are taken among the 288 examined bins; bin 4095 (the
+    advance side's last) and bin 0 (the delay side's first) are neighbours as well: a peak between them is decided by
+    the reference's `>=` between the two sides' maxima (T:693)."""
     scs, bins, n_hops = float(fx.case["scs"]), [int(b) for b in fx.ta_bin[item]], len(fx.case["hops"])
     alts = []
     for h in range(n_hops):

@@ -81,7 +81,10 @@ def run_reference(b, grid):
             side, i = tail, int(ia)
             bins.append(-(HALF - i))
         s = side.numpy().astype(np.float64)
-        pws.append([s[i - 1] if i > 0 else -1.0, s[i], s[i + 1] if i + 1 < HALF else -1.0])
+        # neighbours among the examined bins; bins 4095 (advance side's last) and 0 (delay side's first) are neighbours too
+        below = s[i - 1] if i > 0 else (float(tail[HALF - 1]) if side is head else -1.0)
+        above = s[i + 1] if i + 1 < HALF else (float(head[0]) if side is tail else -1.0)
+        pws.append([below, s[i], above])
         rest = np.delete(s, i)
         margins.append(float((s[i] - rest.max()) / s[i]))
     return ch, scal, bins, pws, margins
