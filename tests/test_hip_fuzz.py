@@ -18,6 +18,27 @@ BASE_SEED = 20261004
 def test_fuzz_case(idx):
     rng = np.random.default_rng([BASE_SEED, idx])
     case, extras = F.draw(rng, 273 if idx % 8 == 0 else 106)
+    _run_case(case, extras, idx)
+
+
+# Cases the long-form fuzzer (tools/fuzz_parity.py) flagged, kept as drawn.  [0]: one PRB, four adjacent pilots, two layers --
+# the powers of bins 4095 and 0 are EQUAL in the oracle's float32 transform (the reference's `>=` takes the delay side);
+# the checker now treats those two bins as neighbours (conftest.ta_tie_alternatives).
+LOGGED_CASES = [
+    {"case": {"name": "fuzz", "n_prb_grid": 52, "hops": [{"dmrs_symbols": [8], "prb_start": 27, "n_prbs": 1, "start_symbol": 0, "n_alloc": 12,
+                                                          "re_masks": [[0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0]]}],
+              "n_layers": 2, "smoothing": "filter", "cfo_compensate": True, "scs": 15000.0, "beta": 1.4125, "n_sym": 14, "seed": 296368357,
+              "cfo_hz": 20.00408490627808, "delay_ns": 51.825950456196864, "noise_var": 0.005},
+     "extras": {"interp": "linear", "layout_ref": False, "cnn_alpha": None, "mmse": None}},
+]
+
+
+@pytest.mark.parametrize("k", range(len(LOGGED_CASES)))
+def test_logged_fuzz_case(k):
+    _run_case(LOGGED_CASES[k]["case"], LOGGED_CASES[k]["extras"], f"logged{k}")
+
+
+def _run_case(case, extras, idx):
     interp = extras["interp"]
     try:
         b = F.realize(case, extras)

@@ -1,0 +1,82 @@
+"""The kernel tiers against each other: the same slots through the plan's default kernel and through the alternative code
+paths its tuning knobs select (environment variables read when a plan is created, csrc/ce_api.hip) -- the re-read path
+instead of the register path, the widest register tier instead of the band's own, the full first TA pass instead of the
+collapsed one, DM-RS symbols re-read instead of parked in the LDS, one TA transform at a time.  Knobs that only move data
+must give bit-identical results; knobs that change a summation order must agree to rounding.  Each knob runs in a fresh
+child process (plans are cached per process)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from srsran_ce_pytorch_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+CASES = [
+    S.case_spec("tier_2hop_200prb", 273, [S.hop_spec([1, 5], 0, 200, 0, 7), S.hop_spec([8, 12], 73, 200, 7, 7)], seed=901),
+    S.case_spec("tier_2hop_3dmrs_150prb", 273, [S.hop_spec([0, 3, 6], 10, 150, 0, 7), S.hop_spec([7, 10, 13], 100, 150, 7, 7)], seed=902),
+    S.case_spec("tier_25prb", 52, [S.hop_spec([2, 11], 10, 25)], seed=903),
+    S.case_spec("tier_2hop_12prb", 52, [S.hop_spec([2], 3, 12, 0, 7), S.hop_spec([9], 30, 12, 7, 7)], seed=904),
+    S.case_spec("tier_L2_40prb", 106, [S.hop_spec([2, 11], 20, 40)], n_layers=2, seed=905),
+    S.case_spec("tier_2hop_L2_12prb", 52, [S.hop_spec([1, 5], 3, 12, 0, 7), S.hop_spec([8, 12], 30, 12, 7, 7)], n_layers=2, seed=906),
+]
+
+CHILD = r'''
+import json, sys
+sys.path[:0] = [%r, %r]
+import numpy as np, torch
+from srsran_ce_pytorch_amd import estimator as E, synth as S
+cases = json.loads(sys.argv[1])
+out = {}
+for c in cases:
+    b = S.build_case(c, 2)
+    g = torch.as_tensor(b.grids, device="cuda:0")[None]
+    r = E.estimate(g, torch.as_tensor(b.pilots, device="cuda:0"), b.beta, b.hop1, b.hop2, b.config)
+    torch.cuda.synchronize()
+    out[c["name"] + "/ch"] = r[0][0].cpu().numpy()
+    for k, t in zip(("noise", "rsrp", "epre", "ta", "cfo"), r[1:]):
+        out[c["name"] + "/" + k] = t[0].cpu().numpy() if t.numel() else np.zeros(0)
+np.savez(sys.argv[2], **out)
+''' % (str(ROOT), str(ROOT / "tests"))
+
+
+def _run(tmp_path, knob):
+    env = dict(os.environ)
+    if knob:
+        env[knob] = "1"
+    dst = tmp_path / f"tier_{knob or 'default'}.npz"
+    p = subprocess.run([sys.executable, "-c", CHILD, json.dumps(CASES), str(dst)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return np.load(dst)
+
+
+@pytest.fixture(scope="module")
+def default_results(tmp_path_factory):
+    return _run(tmp_path_factory.mktemp("tiers"), None)
+
+
+# knob -> results must be bit-identical to the default path's (the knob only changes where data waits or how a transform is pruned?)
+@pytest.mark.parametrize("knob,bitwise", [("CE_NO_PIL_STASH", True), ("CE_TA_LP1", True), ("CE_TA_FULL", False),
+                                          ("CE_FORCE_GENERIC", False), ("CE_FORCE_WIDE", False)])
+def test_alternative_kernel_paths_agree(tmp_path, default_results, knob, bitwise):
+    alt = _run(tmp_path, knob)
+    for c in CASES:
+        n = c["name"]
+        ch0, ch1 = default_results[n + "/ch"], alt[n + "/ch"]
+        if bitwise or knob == "CE_TA_FULL":   # the TA transform never touches the grid
+            assert np.array_equal(ch0, ch1), f"{knob}: {n} channel estimate differs"
+        else:
+            assert np.abs(ch0 - ch1).max() <= 2e-6 * np.abs(ch0).max(), f"{knob}: {n}"
+        assert np.array_equal(default_results[n + "/ta"], alt[n + "/ta"]), f"{knob}: {n} time alignment"
+        for k in ("noise", "rsrp", "epre", "cfo"):
+            a, b = default_results[n + "/" + k], alt[n + "/" + k]
+            if bitwise:
+                assert np.array_equal(a, b), f"{knob}: {n} {k}"
+            else:
+                assert np.allclose(a, b, rtol=2e-6, atol=1e-9 if k != "cfo" else 1e-3), f"{knob}: {n} {k}: {a} vs {b}"
