@@ -478,7 +478,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (L == 1 && n_re <= CE_KPT * CE_THREADS) {
     const int nd = P.hop[0].n_dmrs;
     // received pilots of nd symbols x reg_kpt REs per thread stay in registers (the DM-RS symbols too while they
-    // fit, ce_kernels.hip: PREG): up to 4 symbols in the narrow-band kernels, 3 in the wide one
+    // fit, ce_estimate_kernel.h: PREG): up to 4 symbols in the narrow-band kernels, 3 in the wide one
     bool same = nd <= (P.reg_kpt < CE_KPT ? 4 : 3);
     for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
     if (same) P.reg_nd = nd;
