@@ -66,6 +66,19 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #define STAMP(i)
 #define STAMP_HWID(i)
 #endif
+#if defined(CE_STAMP_STARTUP)
+#define STAMP_TA(i)
+#else
+#define STAMP_TA(i) STAMP(i)
+#endif
+#if defined(CE_STAMPS) && defined(CE_STAMP_STARTUP)   // slots 14 / 15 stamp the start-up instead of the TA stage (tools/stamps.py --startup)
+#define STAMP_STARTUP(i)                                              \
+  do {                                                                \
+    if (threadIdx.x == 0 && a.stamps) a.stamps[(a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local)) * 16 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define STAMP_STARTUP(i)
+#endif
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -817,9 +830,11 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   const int64_t item = a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local);
   load_hop(item, 0, xr, pr);
   if constexpr (PF1) load_hop(item, 1, xr1, pr1);  // hop 2's pilots ride the same round trip (narrow tiers: few registers)
+  STAMP_STARTUP(14);  // plan fields arrived in scalar registers, every pilot load issued
   // the copies' LDS stores come after the pilot requests, so waiting for their data does not delay those
   if (tid < PLAN4) reinterpret_cast<float4*>(smem + lay.off_plan)[tid] = plan_v;
   if (tid < TW4) reinterpret_cast<float4*>(tw256)[tid] = tw_v;
+  STAMP_STARTUP(15);  // plan and twiddle copies arrived
   const int64_t slot = item / a.n_ports;
   const int port = (int)(item - slot * a.n_ports);
   const float2* rx = a.rx + slot * a.rs_b + port * a.rs_r;
@@ -985,7 +1000,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
           for (int i = 0; i < 16; ++i) blk[ta_at<TA_LATE>(a4, i)] = v[i];
         }
         __syncthreads();
-        STAMP(14);
+        STAMP_TA(14);
         if (!hpar) {
           const CeDevHop& bh = lp->hop[h0];
 #pragma unroll 1
@@ -996,7 +1011,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
           }
           __syncthreads();
         }
-        STAMP(15);
+        STAMP_TA(15);
       }
       if (!hpar) {
         const float p0[2] = {pw0, 0.f}, p1[2] = {pw1, 0.f};

@@ -10,8 +10,15 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tools"))
-flags = [a for a in sys.argv[1:] if a.startswith("-")]
-only = [a for a in sys.argv[1:] if not a.startswith("-")] or ["L1 2dmrs filter"]
+sizes = [(64, 4), (8192, 4)]
+args = []
+for a in sys.argv[1:]:
+    if a.startswith("--sizes="):                      # e.g. --sizes=1024x1,8192x4
+        sizes = [tuple(int(v) for v in t.split("x")) for t in a.split("=", 1)[1].split(",")]
+    else:
+        args.append(a)
+flags = [a for a in args if a.startswith("-")]
+only = [a for a in args if not a.startswith("-")] or ["L1 2dmrs filter"]
 from srsran_ce_pytorch_amd import _lib as _L
 _L.build(force=True, extra_flags=["-DCE_STAMPS=1"] + flags, out="/tmp/libce_hip_stamps.so")
 os.environ["CE_HIP_LIB"] = "/tmp/libce_hip_stamps.so"      # never overwrite the shipped library with a diagnostic build
@@ -27,7 +34,7 @@ dev = torch.device("cuda:0")
 for name, case, interp in CASES:
     if not any(o in name for o in only):
         continue
-    for slots, ports in [(64, 4), (8192, 4)]:
+    for slots, ports in sizes:
         h1, h2, cfg = S.numpy_hops(case)
         plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], 14, dev, interp)
         rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
@@ -46,6 +53,11 @@ for name, case, interp in CASES:
         print("  ".join(f"{nm}={np.median(d[:, i]):.2f}" for i, nm in enumerate(names)), flush=True)
         ta_end = np.where(t[:, 11] > ta2, np.where(t[:, 6] > ta2, np.minimum(t[:, 6], t[:, 11]), t[:, 11]), t[:, 6])
         print(f"  time alignment (last hop): radix-16 passes {np.median(ta1 - ta0):.2f} us, bin sums {np.median(ta2 - ta1):.2f} us, arg-max + seconds {np.median(ta_end - ta2):.2f} us")
+        if "-DCE_STAMP_STARTUP" in flags:   # slots 14 / 15: after the plan fields + pilot-load issue, after the plan / twiddle copies
+            e = t[:, 13]
+            print(f"  start-up: workgroup entry after kernel start: median {np.median(e - e.min()):.2f} us, p95 {np.percentile(e - e.min(), 95):.2f}, max {(e - e.min()).max():.2f}; "
+                  f"entry -> plan fields in SGPRs + pilot loads issued {np.median(ta1 - e):.2f} (p95 {np.percentile(ta1 - e, 95):.2f}); "
+                  f"-> plan / twiddle copies in LDS {np.median(ta2 - ta1):.2f} (p95 {np.percentile(ta2 - ta1, 95):.2f}); -> first stage stamp {np.median(t[:, 0] - ta2):.2f}")
         print(f"  kernel entry -> first stage stamp (arguments, plan / twiddle / table copies to LDS, pilot loads issued): median {np.median(t[:, 0] - t[:, 13]):.2f} us, p95 {np.percentile(t[:, 0] - t[:, 13], 95):.2f} us")
         # residency: which CU each workgroup ran on (HW_ID bits 8-15: CU / SH / SE, XCC_ID), how many were resident
         # on a CU on average, and how long a CU waited between one workgroup's last stamp and the next one's first
