@@ -20,7 +20,8 @@ Workloads (BASELINE.json configs):
 Prints ONE JSON line on rank 0 with the driver's fields plus ``roofline`` (HBM; algorithmic bytes
 per launch / HIP-event launch time) and, at N=1, ``cpu_baseline`` (CPU ports of the reference's algorithm --
 the loop-style ce_rule_baseline form and the tensorized form -- timed on the host cores on bounded samples of the same
-workload) and ``secondary`` (the other parity-pinned workloads, a few launches each).
+workload) and ``secondary`` (the other parity-pinned workloads, a few launches each, followed by the two extensions
+without a reference counterpart, each marked ``"parity": "unpinned extension"``).
 """
 from __future__ import annotations
 
@@ -189,8 +190,40 @@ def secondary_lines(E, S, plan, case, rx, pilots, out, n_slots, n_ports, dev, it
     rx_ref = rx.contiguous()
     res.append(timed(plan, rx_ref, pilots, out, n_slots, n_ports, "pusch273_4rx_filter", "[slot][port][sc][sym] (reference layout)", case))
     del rx_ref
+    # The two EXTENSIONS north_star names and the reference does not have -- parity unpinned, never part of the
+    # headline: block LMMSE smoothing in place of the RC FIR (HBM-bound like the rest), and the fp16 Conv2d denoiser kernel
+    # alone on the resident batch of estimates (MFMA-bound; random weights).
+    pm = E.make_plan(hh1, hh2, _with_smoothing(cfgh, "mmse"), case["beta"], 1, case["n_prb_grid"], case["n_sym"], dev)
+    e = timed(pm, rx, pilots, out, n_slots, n_ports, "pusch273_4rx_mmse", "[slot][port][sym][sc]", dict(case, smoothing="mmse"))
+    e["parity"] = "unpinned extension"
+    res.append(e)
+    from srsran_ce_pytorch_amd.denoiser import Denoiser, random_weights
+    dn = Denoiser(random_weights(0), dev)
+    dn(out[0])
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(2):
+        ev0.record()
+        for _ in range(3):
+            dn(out[0])
+        ev1.record()
+        torch.cuda.synchronize()
+        best = min(best, ev0.elapsed_time(ev1) / 3)
+    flops = float(n_slots * n_ports * case["n_prb_grid"] * 12 * case["n_sym"] * DENOISE_FLOP_PER_PIXEL)
+    res.append({"workload": "conv2d_denoiser_kernel", "slots": n_slots, "rx_ports": n_ports, "ms_per_step": best,
+                "slots_per_s": n_slots / (best * 1e-3), "parity": "unpinned extension",
+                "roofline": {"bound": "mfma", "achieved": flops / (best * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flops / (best * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, "alg_flop_per_launch": flops}})
     torch.cuda.synchronize()
     return res
+
+
+def _with_smoothing(cfg, smoothing):
+    import copy
+
+    c = copy.copy(cfg)
+    c.Smoothing = smoothing
+    return c
 
 
 def main():
