@@ -50,6 +50,21 @@ __global__ void patH(float4* p) {
   if (threadIdx.x == 999) pad[0] = 1.f;
   if (threadIdx.x < 252) for (size_t i = threadIdx.x; i < CH4; i += 252) q[i] = v;
 }
+// S: the item's 4 KB chunks in a strided order -- chunk (k mod G) * STRIDE + k div G at step k -- so that consecutive steps of one
+// stream land STRIDE * 4 KB apart (if the HBM channel interleave has that period, a stream then finishes one channel's share of
+// its item -- one DRAM row -- before moving to the next channel instead of revisiting each channel every 64 KB)
+template <int STRIDE>
+__global__ __launch_bounds__(256, 3) void patS(float4* p) {
+  extern __shared__ float pad[];
+  float4* q = p + blockIdx.x * CH4; const float4 v = make_float4(1.f, 2.f, 3.f, (float)blockIdx.x);
+  if (threadIdx.x == 999) pad[0] = 1.f;
+  constexpr int NCH = (int)((CH4 + 255) / 256), G = (NCH + STRIDE - 1) / STRIDE;
+  for (int k = 0; k < G * STRIDE; ++k) {
+    const int c = (k % G) * STRIDE + k / G;
+    const size_t i = (size_t)c * 256 + threadIdx.x;
+    if (c < NCH && i < CH4) q[i] = v;
+  }
+}
 template <typename F> double time_ms(F f, int iters) {
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
   f(); f(); CHECK(hipEventRecord(a)); for (int i = 0; i < iters; ++i) f(); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
@@ -70,6 +85,9 @@ int main() {
       CHECK(hipFuncSetAttribute((const void*)patH, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024));
       t = time_ms([&] { patH<<<n, 256, kb * 1024>>>(p); }, 5); printf("H pattern A, %3d KB LDS (%d WG/CU)  %.3f ms %.0f GB/s\n", kb, 160 / kb > 8 ? 8 : 160 / kb, t, gb / t * 1e3);
     }
+#define RUN_S(ST) do { CHECK(hipFuncSetAttribute((const void*)patS<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 50 * 1024)); \
+    t = time_ms([&] { patS<ST><<<n, 256, 50 * 1024>>>(p); }, 5); printf("S chunk order strided by %4d KB (3 WG/CU) %.3f ms %.0f GB/s\n", ST * 4, t, gb / t * 1e3); } while (0)
+    RUN_S(1); RUN_S(2); RUN_S(4); RUN_S(8); RUN_S(16); RUN_S(32); RUN_S(45); RUN_S(64);
     t = time_ms([&] { patB<<<n, 256>>>(p); }, 5); printf("B wave-contiguous quarters       %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
     t = time_ms([&] { patC<<<n, 256>>>(p); }, 5); printf("C 64 B per lane                  %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
     t = time_ms([&] { patD<<<n, 256>>>(p); }, 5); printf("D 256 lanes x4 unrolled          %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
