@@ -234,4 +234,4 @@ int ce_tu_reg_h2_f1(int op, int key, const CeLaunchCtx& c);
 int ce_tu_gen_h1(int op, int key, const CeLaunchCtx& c);      // re-read path (1-4 layers), every feature set; + the wide headline kernel with extensions
 int ce_tu_gen_h2(int op, int key, const CeLaunchCtx& c);
 // whether the register path (reg_nd > 0) has an instantiation carrying CE_FEAT_EXT for this shape
-static inline bool ce_reg_has_ext(int n_hops, int reg_nd, int reg_kpt) { return n_hops == 1 && reg_nd == 2 && reg_kpt == CE_KPT; }
+static inline bool ce_reg_has_ext(int n_hops, int reg_nd, int reg_kpt) { return n_hops == 1 && reg_nd == 2 && reg_kpt >= 2; }
