@@ -38,6 +38,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #define CE_ABLATE 0   // timing experiments only (tools/ablate.py): 1 TA, 2 smoothing, 4 residual, 8 writer, 16 CFO, 32 input loads, 64 writer without LDS reads
 #endif
 // (register budgets, feature sets and the TA placement policy: ce_plan.h -- the host sizes the LDS by the same rules)
+#ifndef CE_LEAN
+#define CE_LEAN 0         // code-size experiment (never shipped): 2 drops the element-wise writer, 1 also the staged one where the direct writer exists
+#endif
 #ifndef CE_WR_UNROLL
 #define CE_WR_UNROLL 4    // direct writer: iterations whose LDS reads are requested together
 #endif
@@ -1694,7 +1697,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       }
     } else if (direct_ok<SC_STEP>() && lp->interp != CE_INTERP_CNN) {
       if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH, (ce_min_waves(NH, ND, KPT, FEAT, L) >= 5 ? 2 : ce_min_waves(NH, ND, KPT, FEAT, L) == 2 ? 0 : CE_WR_UNROLL)>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);  // (the 96-VGPR tiers have no room for four iterations' operands; 0 = per-element branches: measured 2-4 % faster where only two workgroups share a CU)
-    } else {
+    } else if (!(CE_LEAN == 1 && direct_ok<SC_STEP>())) {
       const float2* HA = scratch + ((hsel[0] * L + lsel[0]) << ch_log2);
       const float2* HB = scratch + ((hsel[1] * L + lsel[1]) << ch_log2);
 #pragma unroll 1
@@ -1725,7 +1728,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         __syncthreads();
       }
     }
-  } else {
+  } else if (!CE_LEAN) {
     // generic writer (any n_sym, hops that share symbols -- the harness's own two-hop convention,
     // scripts/validation/validate_case4.py:85-103 -- for either interpolator): decode (subcarrier, symbol, layer) per
     // element; where the hops' rectangles overlap the later hop wins (T:872-896, src/ce_dl_cnn.py:233-352)

@@ -27,7 +27,8 @@ def per_geometry(rows, field="Counter_Value"):
     for o in order:
         chunk = rows[i:i + o["launches"]]
         i += o["launches"]
-        out.append(st.median(float(r[field]) for r in chunk[1:]) if len(chunk) > 1 else float("nan"))   # first launch = warm-up
+        keep = chunk[-(o.get("keep_last", o["launches"]) - 1):]                    # first launch(es) = warm-up
+        out.append(st.median(float(r[field]) for r in keep) if len(chunk) > 1 else float("nan"))
     return out
 
 
@@ -39,7 +40,7 @@ i = 0
 for r_, o in zip(res, order):
     chunk = tr[i:i + o["launches"]]
     i += o["launches"]
-    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in chunk[1:]]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in chunk[-(o.get("keep_last", o["launches"]) - 1):]]
     r_["kernel"] = chunk[0]["Kernel_Name"].split("(")[1][-40:] if False else chunk[0]["Kernel_Name"][:70]
     r_["kernel_us_median"] = st.median(durs) / 1e3
     r_["alg_GBps"] = o["alg_bytes_per_launch"] / (st.median(durs) * 1e-9) / 1e9

@@ -57,7 +57,7 @@ line = [l for l in open("gpurun_out/r2_bench_same_lease.log") if l.startswith("{
 open(f"{OUT}/{tag}_bench_line.json", "w").write(line)
 bl = json.loads(line)
 out["same_lease_bench"] = {"ms_per_step": bl["ms_per_step"], "kernel_ms": bl["roofline"]["kernel_ms"], "roofline_frac": bl["roofline"]["frac"],
-                           "secondary": [(s["workload"], s["rx_layout"], round(s["ms_per_step"], 4), round(s["roofline"]["frac"], 4)) for s in bl.get("secondary", [])],
+                           "secondary": [(s["workload"], s.get("rx_layout", ""), round(s["ms_per_step"], 4), round(s["roofline"]["frac"], 4)) for s in bl.get("secondary", [])],
                            "cpu_baseline": {k: bl["cpu_baseline"][k] for k in bl.get("cpu_baseline", {}) if k != "sample"}}
 rw = {}
 for l in open("gpurun_out/r2_rwmix.log"):

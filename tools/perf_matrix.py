@@ -20,7 +20,11 @@ for name, case, interp in cases:
     rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
     out = E.estimate_with_plan(plan, rx, pil)
     torch.cuda.synchronize()
-    ms = min(E.time_with_plan(plan, rx, pil, out, 1, 5) for _ in range(2))
+    cold = min(E.time_with_plan(plan, rx, pil, out, 1, 5) for _ in range(2))
+    # short kernels are over in a few ms, before the clocks have settled: keep the GPU busy for ~150 ms, then time 20 launches
+    # (bench.py's own warm-up + 20 steps of a 2.7 ms kernel is past that point)
+    E.time_with_plan(plan, rx, pil, out, 0, max(5, int(150.0 / cold)))
+    ms = min(E.time_with_plan(plan, rx, pil, out, 0, 20) for _ in range(2))
     b = slots * (ports * plan.alg_bytes_per_item + plan.pilot_bytes_per_slot)
-    print(f"{name:36s} {ms:8.3f} ms  {b / ms / 1e6:7.0f} GB/s  {slots / ms * 1e3 / 1e6:6.2f} M slots/s  lds={plan.lds_bytes}", flush=True)
+    print(f"{name:36s} {ms:8.3f} ms  {b / ms / 1e6:7.0f} GB/s  {slots / ms * 1e3 / 1e6:6.2f} M slots/s  lds={plan.lds_bytes}  (first 10 launches: {cold:.3f} ms)", flush=True)
     del rx, pil, out

@@ -18,6 +18,7 @@ from perf_cases import CASES
 WANT = ["L1 2dmrs filter (register path)", "L1 2dmrs none", "L1 2 hops x 2dmrs 200 PRB", "L1 2 hops x 3dmrs 200 PRB",
         "L1 2 hops x 1dmrs 12 PRB in 52", "L1 25 PRB in 52", "L4 2 hops x 2dmrs 136 PRB", "L1 cnn type-2 100 PRB (iterated)"]
 LAUNCHES = 4
+WARM = {"L1 2 hops x 1dmrs 12 PRB in 52": 240, "L1 25 PRB in 52": 320, "configs[1]: L1 2dmrs none, 1024 slots x 1 Rx": 400}
 dev = torch.device("cuda:0")
 order = []
 by_name = {n: (c, i) for n, c, i in CASES}
@@ -29,11 +30,14 @@ def run(tag, case, interp, slots, ports, ref_layout=False):
     rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
     if ref_layout:
         rx = rx.contiguous()
+    # Kernels of a fraction of a millisecond are over before the clocks have settled (8192 x 4 items of a 52-PRB grid: 0.55 ms in
+    # the first ten launches, 0.47 ms after 150 ms of them): WARM[tag] launches, of which the distiller keeps the last LAUNCHES
+    n_launch = WARM.get(tag, LAUNCHES)
     out = E.estimate_with_plan(plan, rx, pil)
-    for _ in range(LAUNCHES - 1):
+    for _ in range(n_launch - 1):
         E.estimate_with_plan(plan, rx, pil, out)
     torch.cuda.synchronize()
-    order.append(dict(name=tag, launches=LAUNCHES, items=slots * ports, lds_bytes=plan.lds_bytes,
+    order.append(dict(name=tag, launches=n_launch, keep_last=LAUNCHES, items=slots * ports, lds_bytes=plan.lds_bytes,
                       alg_bytes_per_launch=slots * (ports * plan.alg_bytes_per_item + plan.pilot_bytes_per_slot)))
     del rx, pil, out
 
