@@ -527,6 +527,9 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     }
   }
   CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
+#ifdef CE_LDS_PAD_DEFAULT   // A/B builds (tools/ab_inproc.py loads several libraries into one process, which share the environment)
+  lay.total += CE_LDS_PAD_DEFAULT & ~15;
+#endif
   if (const char* pad = getenv("CE_LDS_PAD_BYTES")) lay.total += atoi(pad) & ~15;  // tuning knob: lowers the workgroups resident per CU
   if (lay.total > 160 * 1024) { delete p; return fail(CE_ERR_UNSUPPORTED, "plan needs %d B of LDS (> 160 KiB)", lay.total); }
 

@@ -31,14 +31,20 @@
 #define CE_MIN_WAVES_L2H2 3   // re-read path, 2-4 layers x 2 hops (3: 4-11 spilled VGPRs; 2: none, but one workgroup less per CU on narrow bands)
 #endif
 #ifndef CE_MW3_LIMIT
-#define CE_MW3_LIMIT 14  // single hop: up to this many pilot REs x symbols per thread, 3 workgroups per CU (168 VGPRs)
+#define CE_MW3_LIMIT 7   // single hop: up to this many pilot REs x symbols per thread the kernel is built for 3 workgroups per CU (168
+                         // VGPRs); beyond it for CE_MW_WIDE = 2 -- the wide kernels still NEED only 114 / 161 VGPRs and run 4 / 3 per CU, but
+                         // built with the looser bound (and with the TA stage inside the hop loop, ce_ta_late) they measured 2-4 %
+                         // faster at every batch size (profiles/round2_budget_policy_ab.txt: one process, same buffers, +-0.3 %)
+#endif
+#ifndef CE_MW_WIDE
+#define CE_MW_WIDE 2     // single hop beyond CE_MW3_LIMIT: waves per SIMD the allocator leaves room for
 #endif
 #ifndef CE_MW5_LIMIT
 #define CE_MW5_LIMIT 2   // single hop: up to this many pilot REs x symbols per thread, 5 workgroups per CU (<= 96 VGPRs: the FIR shapes spill 1-2
                          // registers for it and gain 10-14 % on <= 25-PRB hops; at 4 per thread the 6-8 spilled registers cost more than the fifth workgroup gives)
 #endif
 #ifndef CE_MW4_LIMIT
-#define CE_MW4_LIMIT 8   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread fit 128 VGPRs: 4 workgroups per CU
+#define CE_MW4_LIMIT 4   // single-hop register-path kernels holding <= this many pilot REs x symbols per thread are built for 4 workgroups per CU (128 VGPRs)
 #endif
 #ifndef CE_NH2_MW4_LIMIT
 #define CE_NH2_MW4_LIMIT 2   // two hops: up to this many pilot REs x symbols per thread, 4 workgroups per CU (4-8 spilled VGPRs; measured +6..12 % on narrow hops, nothing at 4)
@@ -67,7 +73,7 @@ constexpr int CE_FEAT_FIR = 1, CE_FEAT_EXT = 2;
 constexpr int ce_min_waves(int nh, int nd, int kpt, int feat, int layers = 1) {
   const int n = nd * kpt;
   if (nd == 0) return (layers >= 2 && nh == 2) ? CE_MIN_WAVES_L2H2 : CE_MIN_WAVES;
-  if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= CE_MW3_LIMIT ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : 2;
+  if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= CE_MW3_LIMIT ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : CE_MW_WIDE;
   return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
 }
 constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
@@ -79,14 +85,14 @@ constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
 #ifndef CE_TA_LATE
 #define CE_TA_LATE -1   // -1: per-shape policy below; 0 / 1: force (A/B builds)
 #endif
-// Policy from interleaved same-box A/Bs of both placements over tools/perf_cases.py (profiles/round2_ta_placement_ab.txt;
-// resolution of the method ~2 %): late wins 1.5-3 % on the single-hop one-layer shapes, 3-6 % on narrow two-hop ones and
-// for 2-4 layers of one hop; early wins 5-10 % where only two workgroups fit a CU (3 symbols x CE_KPT REs in registers:
-// the late stage keeps a slot from its next item) and 4 % for 2 layers x 2 hops; the rest is within the resolution.
+// Policy from A/Bs of both placements over tools/perf_cases.py -- first between child processes
+// (profiles/round2_ta_placement_ab.txt), then inside one process on the same buffers (tools/ab_inproc.py, +-0.3 %;
+// profiles/round2_budget_policy_ab.txt): late wins 8-17 % on the narrow shapes (one or two hops), 6-7 % on two-hop mid
+// bands and 4 layers, 2-4 % for 2-4 layers x 2 hops; early wins 4 % on the 3-symbol wide kernel and 1-2 % on the wide
+// single-hop kernels built with the 2-wave bound; the rest is within the resolution.
 constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
   if (CE_TA_LATE >= 0) return CE_TA_LATE != 0;
   if (nd > 0 && ce_min_waves(nh, nd, kpt, feat) == 2) return false;
-  if (layers >= 2 && nh == 2) return false;
   // the widest shapes of the 4-workgroup tier (128 VGPRs) with the FIR compiled in: late placement would spill 1-4 registers
   if (nh == 1 && nd * kpt == CE_MW4_LIMIT && (feat & CE_FEAT_FIR)) return false;
   return true;
