@@ -49,6 +49,9 @@
 #ifndef CE_NH2_MW4_LIMIT
 #define CE_NH2_MW4_LIMIT 2   // two hops: up to this many pilot REs x symbols per thread, 4 workgroups per CU (4-8 spilled VGPRs; measured +6..12 % on narrow hops, nothing at 4)
 #endif
+#ifndef CE_NH2_BOUND2_FROM
+#define CE_NH2_BOUND2_FROM 99  // two hops: from this many pilot REs x symbols per thread on, the 2-wave launch bound (DM-RS symbols still parked in the LDS)
+#endif
 #ifndef CE_NH1_PREG_LIMIT
 #define CE_NH1_PREG_LIMIT 99  // single hop: up to this many pilot REs x symbols per thread the DM-RS symbols stay in registers too
 #endif
@@ -74,7 +77,7 @@ constexpr int ce_min_waves(int nh, int nd, int kpt, int feat, int layers = 1) {
   const int n = nd * kpt;
   if (nd == 0) return (layers >= 2 && nh == 2) ? CE_MIN_WAVES_L2H2 : CE_MIN_WAVES;
   if (nh == 1) return n <= CE_MW5_LIMIT ? 5 : n <= CE_MW4_LIMIT ? 4 : n <= CE_MW3_LIMIT ? ((feat & CE_FEAT_FIR) ? CE_MIN_WAVES : CE_MIN_WAVES_LIGHT) : CE_MW_WIDE;
-  return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? CE_MIN_WAVES : 2;
+  return n <= CE_NH2_MW4_LIMIT ? 4 : n < CE_NH2_MW2_FROM ? (n >= CE_NH2_BOUND2_FROM ? 2 : CE_MIN_WAVES) : 2;
 }
 constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
   const int n = nd * kpt;
@@ -92,7 +95,7 @@ constexpr bool ce_pilots_in_regs(int nh, int nd, int kpt) {
 // single-hop kernels built with the 2-wave bound; the rest is within the resolution.
 constexpr bool ce_ta_late(int layers, int nh, int nd, int kpt, int feat) {
   if (CE_TA_LATE >= 0) return CE_TA_LATE != 0;
-  if (nd > 0 && ce_min_waves(nh, nd, kpt, feat) == 2) return false;
+  if (nd > 0 && nh == 1 && ce_min_waves(nh, nd, kpt, feat) == 2) return false;
   // the widest shapes of the 4-workgroup tier (128 VGPRs) with the FIR compiled in: late placement would spill 1-4 registers
   if (nh == 1 && nd * kpt == CE_MW4_LIMIT && (feat & CE_FEAT_FIR)) return false;
   return true;
