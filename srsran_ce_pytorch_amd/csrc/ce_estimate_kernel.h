@@ -41,6 +41,12 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_LEAN
 #define CE_LEAN 0         // code-size experiment (never shipped): 2 drops the element-wise writer, 1 also the staged one where the direct writer exists
 #endif
+#ifndef CE_WR_BR_UNROLL
+#define CE_WR_BR_UNROLL 2 // direct writer with per-element branches: unrolled iterations
+#endif
+#ifndef CE_WR_WIDE
+#define CE_WR_WIDE 0      // the same for the kernels built with the 2-wave bound (0 = per-element branches)
+#endif
 #ifndef CE_WR_UNROLL
 #define CE_WR_UNROLL 4    // direct writer: iterations whose LDS reads are requested together
 #endif
@@ -661,7 +667,7 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
       for (int it = lo_it; it < hi_it; ++it) body(std::false_type{});
       for (int it = hi_it; it < n_iter; ++it) { store_f4(o, z4); o += ACTIVE; }
     } else {
-#pragma unroll 2
+#pragma unroll CE_WR_BR_UNROLL
       for (int it = 0; it < n_iter; ++it) body(std::true_type{});
     }
   }
@@ -1696,7 +1702,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         }
       }
     } else if (direct_ok<SC_STEP>() && lp->interp != CE_INTERP_CNN) {
-      if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH, (ce_min_waves(NH, ND, KPT, FEAT, L) >= 5 ? 2 : ce_min_waves(NH, ND, KPT, FEAT, L) == 2 ? 0 : CE_WR_UNROLL)>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);  // (the 96-VGPR tiers have no room for four iterations' operands; 0 = per-element branches: measured 2-4 % faster where only two workgroups share a CU)
+      if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH, (ce_min_waves(NH, ND, KPT, FEAT, L) >= 5 ? 2 : ce_min_waves(NH, ND, KPT, FEAT, L) == 2 ? CE_WR_WIDE : CE_WR_UNROLL)>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);  // (the 96-VGPR tiers have no room for four iterations' operands; 0 = per-element branches: measured 2-4 % faster where only two workgroups share a CU)
     } else if (!(CE_LEAN == 1 && direct_ok<SC_STEP>())) {
       const float2* HA = scratch + ((hsel[0] * L + lsel[0]) << ch_log2);
       const float2* HB = scratch + ((hsel[1] * L + lsel[1]) << ch_log2);
