@@ -165,6 +165,9 @@ def secondary_lines(E, S, plan, case, rx, pilots, out, n_slots, n_ports, dev, it
 
     def timed(pl, rx_, pil_, out_, slots, ports, name, layout, workload_case):
         ms = min(E.time_with_plan(pl, rx_, pil_, out_, 1, iters) for _ in range(2))
+        if ms < 1.0:   # a sub-millisecond launch: five of them are over before the clocks have settled after the set-up above
+            E.time_with_plan(pl, rx_, pil_, out_, 0, int(30.0 / ms))
+            ms = min(E.time_with_plan(pl, rx_, pil_, out_, 0, 20) for _ in range(3))
         b = slots * (ports * pl.alg_bytes_per_item + pl.pilot_bytes_per_slot)
         ach = b / (ms * 1e-3) / 1e9
         return {"workload": name, "slots": slots, "rx_ports": ports, "smoothing": workload_case["smoothing"], "ms_per_step": ms,
