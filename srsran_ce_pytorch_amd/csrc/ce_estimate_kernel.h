@@ -41,6 +41,9 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_LEAN
 #define CE_LEAN 0         // code-size experiment (never shipped): 2 drops the element-wise writer, 1 also the staged one where the direct writer exists
 #endif
+#ifndef CE_PRIO
+#define CE_PRIO 0         // wave-priority experiments (0 = none): 1 writer high, 2 estimation stages high
+#endif
 #ifndef CE_WR_BR_UNROLL
 #define CE_WR_BR_UNROLL 2 // direct writer with per-element branches: unrolled iterations
 #endif
@@ -836,6 +839,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
     }
   };
   if (blockIdx.x >= a.n_local) return;  // the grid is exactly n_local workgroups
+#if CE_PRIO == 2
+  __builtin_amdgcn_s_setprio(3);   // experiment: the estimation stages win, so that a workgroup reaches its stores sooner
+#endif
   const int64_t item = a.item0 + item_of(blockIdx.x, a.n_ports, a.n_local);
   load_hop(item, 0, xr, pr);
   if constexpr (PF1) load_hop(item, 1, xr1, pr1);  // hop 2's pilots ride the same round trip (narrow tiers: few registers)
@@ -1543,6 +1549,11 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   __syncthreads();
 
   STAMP(8);
+#if CE_PRIO == 1
+  __builtin_amdgcn_s_setprio(3);   // experiment: the waves that feed the store stream win the issue arbitration
+#elif CE_PRIO == 2
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // ---------------------------------------------------------------- interpolate + replicate + CFO ramp (S10)
   const int n_sym = lp->n_sym;
   const int row = n_sym * L;  // complex values per subcarrier
@@ -1779,6 +1790,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
     }
   }
   STAMP(10);
+#if CE_PRIO == 1
+  __builtin_amdgcn_s_setprio(0);
+#endif
   if constexpr (TA_LATE) {
     // ---------------------------------------------------------------- time alignment of each hop (S8)
     // Nothing the grid needs depends on it, so it runs here, while this workgroup's stores drain: the read ->
