@@ -17,7 +17,7 @@ INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = Path(os.environ.get("CE_HIP_LIB", CSRC / "libce_hip.so"))   # override: diagnostic builds (tools/)
 # the estimation kernel template (ce_estimate_kernel.h) is instantiated in slices, one translation unit each, so the
 # units compile concurrently (ce_inst.inc)
-SOURCES = ["ce_api.hip", "ce_denoise.hip", "ce_inst_reg_h1_f0.hip", "ce_inst_reg_h1_f1.hip", "ce_inst_reg_h2_f0.hip",
+SOURCES = ["ce_api.hip", "ce_denoise.hip", "ce_inst_reg_h1_f0.hip", "ce_inst_reg_h1_f1.hip", "ce_inst_reg_h1_f1w.hip", "ce_inst_reg_h2_f0.hip",
            "ce_inst_reg_h2_f1.hip", "ce_inst_gen_h1.hip", "ce_inst_gen_h2.hip"]
 HEADERS = ["ce_plan.h", "ce_estimate_kernel.h", "ce_inst.inc"]
 
@@ -68,7 +68,9 @@ EXPORTS_DENOISE = ["ce_denoiser_create", "ce_denoiser_destroy", "ce_denoise_batc
 
 # per-source compiler flags: the denoiser's MFMA results feed vector instructions straight away, so keep them in
 # VGPRs (the default AGPR form costs four v_accvgpr_read per 16x16 tile in a kernel bound by vector-instruction issue)
-EXTRA_FLAGS = {"ce_denoise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"ce_denoise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # wide single-hop FIR kernels (the headline's among them): max-ILP scheduling, 2-3 % faster in process; the narrow tiers lose with it
+               "ce_inst_reg_h1_f1w.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: Path | None = None) -> Path:

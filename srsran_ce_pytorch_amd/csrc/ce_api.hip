@@ -144,7 +144,7 @@ static int kernel_op(int op, const CeDevPlan& P, const CeLaunchCtx& c) {
   const bool two = P.n_hops == 2;
   if (P.reg_nd == 0 || P.feat == 3) return two ? ce_tu_gen_h2(op, key, c) : ce_tu_gen_h1(op, key, c);
   if (P.feat == 0) return two ? ce_tu_reg_h2_f0(op, key, c) : ce_tu_reg_h1_f0(op, key, c);
-  return two ? ce_tu_reg_h2_f1(op, key, c) : ce_tu_reg_h1_f1(op, key, c);
+  return two ? ce_tu_reg_h2_f1(op, key, c) : P.reg_kpt >= 4 ? ce_tu_reg_h1_f1w(op, key, c) : ce_tu_reg_h1_f1(op, key, c);
 }
 
 #if defined(CE_STAMPS)

@@ -237,7 +237,8 @@ struct CeLaunchCtx {
 #define CE_KERNEL_KEY(feat, layers, reg_nd, reg_kpt) \
   ((feat) * 10000 + (layers) * 1000 + (reg_nd) * 10 + ((reg_nd) && (reg_kpt) < CE_KPT ? (reg_kpt) : 0))
 int ce_tu_reg_h1_f0(int op, int key, const CeLaunchCtx& c);   // register path (one layer), one hop, none / mean smoothing
-int ce_tu_reg_h1_f1(int op, int key, const CeLaunchCtx& c);   //                               ... + RC filter
+int ce_tu_reg_h1_f1(int op, int key, const CeLaunchCtx& c);   //                               ... + RC filter, band tiers KPT 1 / 2
+int ce_tu_reg_h1_f1w(int op, int key, const CeLaunchCtx& c);  //                               ... + RC filter, band tiers KPT 4 / CE_KPT
 int ce_tu_reg_h2_f0(int op, int key, const CeLaunchCtx& c);   // two hops
 int ce_tu_reg_h2_f1(int op, int key, const CeLaunchCtx& c);
 int ce_tu_gen_h1(int op, int key, const CeLaunchCtx& c);      // re-read path (1-4 layers), every feature set; + the wide headline kernel with extensions
