@@ -66,21 +66,33 @@ TA_TIE_RATIO = 1e-5
 
 
 def ta_tie_alternatives(fx, item):
-    """TA values that differ from the reference's by ONE bin in ONE hop towards a neighbour whose power, in the
+    """TA values that differ from the reference's by ONE bin per hop towards a neighbour whose power, in the
     reference's own transform, is within TA_TIE_RATIO of the winner's -- computed with the reference's arithmetic
     (T:698, T:918-919) so the comparison stays exact.  Neighbours are taken among the 288 examined bins; bin 4095 (the
     advance side's last) and bin 0 (the delay side's first) are neighbours as well: a peak between them is decided by
     the reference's `>=` between the two sides' maxima (T:693)."""
     scs, bins, n_hops = float(fx.case["scs"]), [int(b) for b in fx.ta_bin[item]], len(fx.case["hops"])
-    alts = []
+    return ta_alternatives_from(bins, [[float(x) for x in fx.ta_pw[item][h]] for h in range(n_hops)], scs)
+
+
+def ta_alternatives_from(bins, powers, scs):
+    """All TA values obtained by moving, in each hop independently, the reference's bin to a neighbour whose power (in the
+    reference's own transform, `powers[h] = [below, chosen, above]`) is within TA_TIE_RATIO of the chosen bin's -- every
+    combination except "nothing moved" (two one-PRB hops can each sit on a tie: the long-form fuzzer met one)."""
+    import itertools
+    n_hops = len(bins)
+    moves = []
     for h in range(n_hops):
-        lo, top, hi = [float(x) for x in fx.ta_pw[item][h]]
-        for d, p in ((-1, lo), (+1, hi)):
-            if p >= (1.0 - TA_TIE_RATIO) * top and p >= 0.0:
-                ta = 0.0
-                for k in range(n_hops):
-                    ta = ta + float(bins[k] + (d if k == h else 0)) / 4096.0 / scs
-                alts.append(ta / 2.0 if n_hops == 2 else ta)
+        lo, top, hi = powers[h]
+        moves.append([0] + [d for d, p in ((-1, lo), (+1, hi)) if p >= (1.0 - TA_TIE_RATIO) * top and p >= 0.0])
+    alts = []
+    for combo in itertools.product(*moves):
+        if not any(combo):
+            continue
+        ta = 0.0
+        for k in range(n_hops):
+            ta = ta + float(bins[k] + combo[k]) / 4096.0 / float(scs)
+        alts.append(ta / 2.0 if n_hops == 2 else ta)
     return alts
 
 

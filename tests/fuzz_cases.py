@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from conftest import TA_TIE_RATIO, check_outputs
+from conftest import TA_TIE_RATIO, check_outputs, ta_alternatives_from
 from srsran_ce_pytorch_amd import synth as S
 
 SINGLE = [S.TYPE1_CDM0, S.TYPE1_CDM1, S.TYPE2_CDM0, S.TYPE2_CDM1, [1] * 12, [1, 0, 0, 0] * 3, [0, 0, 1, 0] * 3,
@@ -79,7 +79,7 @@ def realize(case, extras, n_items=2):
 
 def compare_item(case, b, got_ch, got_sc, ref, stages, what):
     """The suite's protocol (conftest.check_outputs) plus what random narrow bands need: a TA neighbour bin the ORACLE's
-    own transform puts within TA_TIE_RATIO of its arg-max is accepted (one bin, one hop); 1-2 pilots give a flat /
+    own transform puts within TA_TIE_RATIO of its arg-max is accepted (one bin per hop); 1-2 pilots give a flat /
     periodic |IFFT| whose arg-max is arbitrary on every side; the CFO has a float32 floor of ~3e-7 rad whatever the
     angle; "mean" smoothing can cancel to a small band mean, so its rounding scales with |H| ~ 1, not with the result."""
     n_pil, n_hops, scs = b.pilots.shape[0], len(case["hops"]), case["scs"]
@@ -92,15 +92,7 @@ def compare_item(case, b, got_ch, got_sc, ref, stages, what):
     if n_pil <= 2:
         got[3] = rs[3]
     else:
-        bins = [st["ta_bin"] for st in stages]
-        for h, st in enumerate(stages):
-            lo, top, hi = st["ta_pw"]
-            for d, p in ((-1, lo), (+1, hi)):
-                if p >= (1.0 - TA_TIE_RATIO) * top and p >= 0.0:
-                    ta = 0.0
-                    for k in range(n_hops):
-                        ta = ta + float(bins[k] + (d if k == h else 0)) / 4096.0 / float(scs)
-                    alts.append(ta / 2.0 if n_hops == 2 else ta)
+        alts = ta_alternatives_from([st["ta_bin"] for st in stages], [st["ta_pw"] for st in stages], scs)
     if np.isfinite(rs[4]) and abs(got[4] - rs[4]) <= 5e-8 * scs:
         got[4] = rs[4]
     cond = max(1.0, 0.7 / float(np.abs(ref[0]).max())) if case["smoothing"] == "mean" else 1.0

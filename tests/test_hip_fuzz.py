@@ -30,6 +30,9 @@ LOGGED_CASES = [
               "n_layers": 2, "smoothing": "filter", "cfo_compensate": True, "scs": 15000.0, "beta": 1.4125, "n_sym": 14, "seed": 296368357,
               "cfo_hz": 20.00408490627808, "delay_ns": 51.825950456196864, "noise_var": 0.005},
      "extras": {"interp": "linear", "layout_ref": False, "cnn_alpha": None, "mmse": None}},
+    # [1]: two one-PRB hops (four adjacent pilots each), each on a tie of its own -- hop 1's bins 60 and 61 EQUAL in the oracle's
+    # transform, hop 2's bins 48 and 49 within 2.4e-7: the checker now allows one tied-neighbour move PER HOP
+    {"case": {"name": "fuzz", "n_prb_grid": 273, "hops": [{"dmrs_symbols": [0, 4, 6], "prb_start": 144, "n_prbs": 1, "start_symbol": 0, "n_alloc": 10, "re_masks": [[0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0]]}, {"dmrs_symbols": [7], "prb_start": 184, "n_prbs": 1, "start_symbol": 5, "n_alloc": 9, "re_masks": [[0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0]]}], "n_layers": 1, "smoothing": "filter", "cfo_compensate": True, "scs": 30000.0, "beta": 1.4125, "n_sym": 14, "seed": 718188862, "cfo_hz": 345.8305489523933, "delay_ns": 335.197121631845, "noise_var": 0.005}, "extras": {"interp": "linear", "layout_ref": False, "cnn_alpha": None, "mmse": None}},
 ]
 
 
