@@ -14,6 +14,13 @@
 
 #include "ce_plan.h"
 
+#ifndef CE_LDS_BIG_BYTES
+#define CE_LDS_BIG_BYTES (80 * 1024)   // two workgroups per CU
+#endif
+#ifndef CE_LDS_BIG_ITEMS
+#define CE_LDS_BIG_ITEMS 8192          // work items from which a launch of the wide none / mean kernel asks for it
+#endif
+
 struct ce_plan {
   ce_plan_desc desc;
   CeDevPlan host;
@@ -24,6 +31,7 @@ struct ce_plan {
   ce_plan_info info;
   int device = 0;
   int grid_cap = 1;   // persistent grid: CUs x workgroups resident per CU
+  int lds_big = 0;    // > 0: dynamic LDS requested for launches of >= CE_LDS_BIG_ITEMS work items (fewer workgroups per CU)
   std::vector<float> mmse_w;  // extension: Re | Im of W[m][k], CE_MMSE_BLOCK^2 each
 };
 
@@ -582,6 +590,17 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     }
     e = (hipError_t)kr;
   }
+  // The wide single-hop none / mean kernel needs 114 VGPRs and little LDS: four workgroups fit a CU, but from a few rounds of
+  // work on it runs 2-4 % faster with two (in-process A/B: 2048 x 4 items -4.3 %, 8192 x 4 -2.1 %; 1024 x 1 +2.5 %), so large
+  // launches request as much dynamic LDS as leaves room for two.  Placement only: results are unaffected.
+  if (e == hipSuccess && P.n_hops == 1 && L == 1 && P.reg_nd == 2 && P.reg_kpt == CE_KPT && P.feat == 0 && lay.total <= CE_LDS_BIG_BYTES &&
+      !getenv("CE_NO_LDS_BIG")) {  // env: A/B knob
+    int nb2 = 1;
+    CeLaunchCtx c2 = {};
+    c2.lds = CE_LDS_BIG_BYTES;
+    c2.blocks_per_cu = &nb2;
+    if (kernel_op(CE_OP_PREPARE, P, c2) == 0) p->lds_big = CE_LDS_BIG_BYTES;   // (raises the kernel's dynamic-LDS limit on this device)
+  }
   if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device);
   p->grid_cap = blocks_per_cu * n_cu;
   if (e != hipSuccess) {
@@ -673,7 +692,7 @@ static int launch_batch(const ce_plan* plan, const void* rx, const int64_t rx_st
   if (scope.err != hipSuccess) return fail(CE_ERR_HIP, "device %d: %s", plan->device, hipGetErrorString(scope.err));
   CeLaunchCtx c = {};
   c.dplan = plan->dev_plan; c.re_idx = plan->dev_re_idx; c.ta_inv = plan->dev_ta_inv; c.tw = plan->dev_tw;
-  c.args = &a; c.lds = plan->info.lds_bytes; c.stream = (hipStream_t)stream;
+  c.args = &a; c.lds = (plan->lds_big && a.n_items >= CE_LDS_BIG_ITEMS) ? plan->lds_big : plan->info.lds_bytes; c.stream = (hipStream_t)stream;
   int e = kernel_op(CE_OP_LAUNCH, plan->host, c);
   if (e != 0) return fail(CE_ERR_HIP, "kernel launch failed: %s", e > 0 ? hipGetErrorString((hipError_t)e) : "no kernel for this (layers, hops)");
   return CE_OK;

@@ -147,3 +147,23 @@ def test_large_plan_survives_a_later_small_plan_of_the_same_kernel():
     b = outs[0][2]
     ref = O.srs_channel_estimator(b.grids[0], b.pilots, b.beta, b.hop1, b.hop2, b.config)
     assert np.abs(outs[2][1][0, 0].cpu().numpy() - ref[0]).max() <= 2e-5 * np.abs(ref[0]).max()
+
+
+def test_large_none_launch_with_the_big_lds_request_equals_small_launches():
+    """From 8192 work items on, launches of the wide none / mean kernel ask for enough dynamic LDS to leave room for two
+    workgroups per CU only (ce_api.hip: lds_big).  Placement only: a 2304 x 4 launch must reproduce, bit for bit, the same
+    slots estimated 512 at a time (below the threshold)."""
+    case = S.bench_case("none", 1, seed=97)
+    h1, h2, cfg = S.numpy_hops(case)
+    dev = torch.device(DEV)
+    plan = E.make_plan(h1, h2, cfg, case["beta"], 1, 273, 14, dev)
+    rx, pil = S.torch_inputs(case, 2304, 4, dev, seed=97)
+    big = E.estimate_with_plan(plan, rx, pil)
+    torch.cuda.synchronize()
+    for s0 in (0, 1024, 1792):
+        sl = slice(s0, s0 + 512)
+        sub = E.estimate_with_plan(plan, rx[sl], pil[sl])
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(sub[0]), torch.view_as_real(big[0][sl]))
+        for a, b in zip(sub[1:], big[1:]):
+            assert torch.equal(a, b[sl])
