@@ -265,12 +265,20 @@ def main():
     # CE_BENCH_REHEARSE=1 (dev only, 1-GPU box): all ranks share cuda:0 and rendezvous over gloo, to exercise the
     # multi-rank control flow where only one GPU exists; its numbers mean nothing
     rehearse = os.environ.get("CE_BENCH_REHEARSE") == "1"
+    # CE_BENCH_FORCE_PG=1: take the N > 1 branch at ANY world size -- RCCL bootstrap (init_process_group("nccl")), the
+    # device-tensor all_reduce(MAX) of the timing, dist.barrier() and destroy_process_group() then run at world size 1 on a
+    # one-GPU box exactly as they will in the driver's 8-GPU job (tests/test_bench_multirank.py; profiles/round3_bench_rccl_1rank.json)
+    use_pg = world > 1 or os.environ.get("CE_BENCH_FORCE_PG") == "1"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        # an RCCL / rendezvous failure propagates (non-zero exit with the library's own message); nothing here retries
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -292,7 +300,7 @@ def main():
             denoiser(out[0])
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -322,7 +330,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearse else ""),
         "config": {"workload": args.workload, "n_prb": 273, "n_sc": plan.n_sc, "n_sym": plan.n_sym, "dmrs_symbols": [2, 11],
                    "layers": 1, "rx_ports": n_ports, "smoothing": wl["smoothing"], "interp": wl.get("interp", "linear"), "slots_per_gpu": n_slots,
-                   "global_slots": world * n_slots, "rx_layout": "[slot][port][sym][sc]", "parallelism": f"slot-shard x{world}, no collective"},
+                   "global_slots": world * n_slots, "rx_layout": "[slot][port][sym][sc]", "parallelism": f"slot-shard x{world}, no collective",
+                   "process_group": ("gloo (rehearsal)" if rehearse else "nccl (RCCL)") if use_pg else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "ce_estimate_kernel<1,1,2,7,%d>" % (1 if wl["smoothing"] == "filter" else 3 if wl["smoothing"] == "mmse" else 0), "kernel_ms": kernel_ms,
@@ -351,7 +360,7 @@ def main():
         line["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

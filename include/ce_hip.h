@@ -160,6 +160,21 @@ int ce_time_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[
                   double* rsrp, double* epre, double* ta, double* cfo_hz, void* stream, int32_t warmup,
                   int32_t iters, double* avg_ms);
 
+/*
+ * Tuning knobs.  libce_hip.so reads NO environment variable.  The diagnostic build of the same sources
+ * (csrc/libce_hip_knobs.so, compiled with -DCE_TUNING_KNOBS; loaded by tests/test_hip_tiers.py and the dev tools through
+ * CE_HIP_LIB=<path>, which srsran_ce_pytorch_amd/_lib.py honours) reads these when a plan is created -- each selects an
+ * alternative kernel path of the same arithmetic, for A/B timing and for testing the tiers against each other:
+ *   CE_FORCE_GENERIC   re-read path (ND = 0) instead of the register path
+ *   CE_FORCE_WIDE      widest register tier (KPT = 7) instead of the band's own
+ *   CE_TA_FULL         full first radix-16 pass of the time-alignment transform instead of the collapsed narrow-band one
+ *   CE_TA_LP1          one time-alignment transform at a time (no layer- / hop-parallel form)
+ *   CE_NO_PIL_STASH    DM-RS symbols re-read per stage instead of parked in the LDS
+ *   CE_CNN_GENERAL     ce_dl_cnn in-painting always iterated (no closed forms)
+ *   CE_LDS_PAD_BYTES   extra dynamic LDS per workgroup (lowers the workgroups resident per CU)
+ *   CE_NO_LDS_BIG      no 80 KB LDS request for large launches of the wide none / mean kernel
+ * Knobs are not part of the host-side plan-cache key: set them before the process creates its first plan.
+ */
 const char* ce_last_error(void);
 int ce_abi_version(void);
 

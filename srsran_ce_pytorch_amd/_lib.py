@@ -15,6 +15,10 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = Path(os.environ.get("CE_HIP_LIB", CSRC / "libce_hip.so"))   # override: diagnostic builds (tools/)
+# the same library with the tuning / A-B knobs of include/ce_hip.h compiled in (-DCE_TUNING_KNOBS: environment variables
+# read at plan creation).  Diagnostic only -- tests/test_hip_tiers.py and the dev tools load it through CE_HIP_LIB; the
+# shipped libce_hip.so never reads the environment.
+KNOBS_LIB_PATH = CSRC / "libce_hip_knobs.so"
 # the estimation kernel template (ce_estimate_kernel.h) is instantiated in slices, one translation unit each, so the
 # units compile concurrently (ce_inst.inc)
 SOURCES = ["ce_api.hip", "ce_denoise.hip", "ce_inst_reg_h1_f0.hip", "ce_inst_reg_h1_f1.hip", "ce_inst_reg_h1_f1w.hip", "ce_inst_reg_h2_f0.hip",
@@ -80,9 +84,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: Path 
 
     srcs = [CSRC / s for s in SOURCES]
     deps = srcs + [CSRC / h for h in HEADERS] + [INCLUDE / "ce_hip.h", INCLUDE / "ce_denoise.h", Path(__file__)]
-    target = Path(out) if out is not None else LIB_PATH
-    if out is None and not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return LIB_PATH
+    shipped = CSRC / "libce_hip.so"                         # build() always writes the in-tree library, whatever CE_HIP_LIB selects for loading
+    target = Path(out) if out is not None else shipped
+    if out is None and not force and all(t.exists() and all(t.stat().st_mtime >= d.stat().st_mtime for d in deps) for t in (shipped, KNOBS_LIB_PATH)):
+        return shipped
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     objdir = CSRC / ".build" if out is None else Path(str(target) + ".obj")   # diagnostic builds (tools/) keep their own objects
     objdir.mkdir(exist_ok=True)
@@ -96,12 +101,28 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: Path 
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+    def compile_knobs() -> Path:                               # ce_api.hip is the only unit that looks at the knobs
+        obj = objdir / "ce_api_knobs.o"
+        cmd = common + ["-DCE_TUNING_KNOBS=1", "-c", str(CSRC / "ce_api.hip"), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs) + 1, os.cpu_count() or 4)) as pool:
+        knobs_obj = pool.submit(compile_knobs) if out is None else None
         objs = list(pool.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(target)] + [str(o) for o in objs]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        knobs_obj = knobs_obj.result() if knobs_obj is not None else None
+
+    def link(objects, dst):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(dst)] + [str(o) for o in objects]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+
+    link(objs, target)
+    if knobs_obj is not None:
+        link([knobs_obj if o.name == "ce_api.o" else o for o in objs], KNOBS_LIB_PATH)
     return target
 
 

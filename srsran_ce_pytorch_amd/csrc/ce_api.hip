@@ -30,12 +30,24 @@ struct ce_plan {
   float2* dev_tw = nullptr;
   ce_plan_info info;
   int device = 0;
-  int grid_cap = 1;   // persistent grid: CUs x workgroups resident per CU
   int lds_big = 0;    // > 0: dynamic LDS requested for launches of >= CE_LDS_BIG_ITEMS work items (fewer workgroups per CU)
   std::vector<float> mmse_w;  // extension: Re | Im of W[m][k], CE_MMSE_BLOCK^2 each
 };
 
 thread_local std::string g_err;
+
+// Tuning / A-B knobs (environment variables read when a plan is created).  They exist only in the diagnostic library
+// (libce_hip_knobs.so, built with -DCE_TUNING_KNOBS; tests/test_hip_tiers.py and the dev tools load it through CE_HIP_LIB):
+// the shipped libce_hip.so never looks at the environment, so a stray variable cannot change its kernel selection or LDS
+// sizing.  Listed in include/ce_hip.h.
+static inline const char* ce_knob(const char* name) {
+#ifdef CE_TUNING_KNOBS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 namespace {
 
@@ -308,7 +320,9 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       // bin, the residues stay), and a band that then ends below subcarrier 256 / 512 has one / two non-zero inputs per
       // 16-point transform of the first radix-16 pass, which collapses to a twiddle multiply (ce_estimate_kernel.h).
       const int shift = pos_min & ~15, nb = (pos_max - shift) / 256 + 1;
-      H.ta_win = (nb <= 2 && !getenv("CE_TA_FULL")) ? (uint32_t)shift | ((uint32_t)nb << 16) : 0u;  // env: A/B knob
+      // (the collapsed pass probes subcarriers shift .. shift + 256 nb - 1 of this hop's subcarrier -> pilot table: a band at
+      // the top of a grid wider than 3840 subcarriers must keep those inside the table's CE_FFT_SIZE entries)
+      H.ta_win = (nb <= 2 && shift + 256 * nb <= CE_FFT_SIZE && !ce_knob("CE_TA_FULL")) ? (uint32_t)shift | ((uint32_t)nb << 16) : 0u;
     }
     // nSamples = nSyms + sum(CPDs(i0+1 .. i1)), CPDs = cp_ms * (scs/1000) (T:395-426, called with scs/1000 at T:599)
     if (H.has_cfo) {
@@ -414,7 +428,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     // in-painting + low-pass is the 5-tap binomial [1 4 6 4 1] / 16 over the linear fill of T:311-338, pilots restored
     // (mode 2).  Shorter bands, or sparser masks, depend on the exact iteration count and are iterated as before.
     P.cnn_comb2 = 0;
-    if (d->interp == CE_INTERP_CNN && !getenv("CE_CNN_GENERAL")) {  // env: tuning / A-B knob
+    if (d->interp == CE_INTERP_CNN && !ce_knob("CE_CNN_GENERAL")) {
       bool comb2 = true, converges = true;
       for (int h = 0; h < d->n_hops; ++h)
         for (int c = 0; c < n_cdm; ++c) {
@@ -481,7 +495,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   P.sym_overlap = (d->n_hops == 2 && std::max(P.hop[0].sym0, P.hop[1].sym0) < std::min(P.hop[0].sym1, P.hop[1].sym1)) ? 1 : 0;
   // register path: one layer (two layers' pilots would spill: measured slower than re-reading), every hop
   // with the same DM-RS symbol count, band fits CE_KPT pilot REs per thread
-  P.reg_kpt = getenv("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : n_re <= 2 * CE_THREADS ? 2 : n_re <= 4 * CE_THREADS ? 4 : CE_KPT);  // env: tuning knob
+  P.reg_kpt = ce_knob("CE_FORCE_WIDE") ? CE_KPT : (n_re <= CE_THREADS ? 1 : n_re <= 2 * CE_THREADS ? 2 : n_re <= 4 * CE_THREADS ? 4 : CE_KPT);
   P.reg_nd = 0;
   if (L == 1 && n_re <= CE_KPT * CE_THREADS) {
     const int nd = P.hop[0].n_dmrs;
@@ -491,7 +505,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     for (int h = 1; h < d->n_hops; ++h) same = same && P.hop[h].n_dmrs == nd;
     if (same) P.reg_nd = nd;
   }
-  if (getenv("CE_FORCE_GENERIC")) P.reg_nd = 0;  // tuning knob: always take the re-read path
+  if (ce_knob("CE_FORCE_GENERIC")) P.reg_nd = 0;  // always take the re-read path
   // feature set the kernel must carry (ce_estimate_kernel.h): the register-path kernels are built without the
   // extensions (one exception: the wide 2-symbol shape), plans that need them take the re-read path
   P.feat = d->smoothing == CE_SMOOTH_FILTER ? 1 : 0;
@@ -510,7 +524,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     const int sb2 = std::max(P.scratch_bytes, 2 * 8 * ce_ta_row(late) * 8);
     const int waves = ce_min_waves(P.n_hops, P.reg_nd, kpt, P.feat & 1, L);
     const bool shape = L >= 2 || (d->n_hops == 2 && late);
-    if (shape && !getenv("CE_TA_LP1") && nres_max <= 8 &&   // env: A/B knob
+    if (shape && !ce_knob("CE_TA_LP1") && nres_max <= 8 &&
         ((ce_lds_layout(P.n_hops, L, P.n_re_pad, sb2).total + 2047) & ~2047) * waves <= 160 * 1024) {  // LDS is granted in 2 KB steps (measured: 3 x 52 128 B fit a CU, 3 x 54 176 B do not)
       P.ta_lp = 2;
       P.scratch_bytes = sb2;
@@ -519,7 +533,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   // Register-path kernels that cannot also hold the DM-RS symbols in registers (ce_pilots_in_regs) park the current hop's
   // in the scratch behind whatever the smoothing stage uses there, when that fits the kernel's LDS share
   P.pil_stash = 0;
-  if (P.reg_nd >= 2 && !ce_pilots_in_regs(P.n_hops, P.reg_nd, P.reg_kpt) && !getenv("CE_NO_PIL_STASH")) {  // env: A/B knob
+  if (P.reg_nd >= 2 && !ce_pilots_in_regs(P.n_hops, P.reg_nd, P.reg_kpt) && !ce_knob("CE_NO_PIL_STASH")) {
     int smooth_need = 512;  // windowed FIR: virtual pilots of up to two rows
     if (d->smoothing == CE_SMOOTH_FILTER && !P.filt_windowed) smooth_need = P.filt_lpp * P.ext_len * 8;
     if (d->interp == CE_INTERP_CNN && P.cnn_alpha > 0.f) smooth_need = std::max(smooth_need, n_re * 8);
@@ -538,7 +552,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
 #ifdef CE_LDS_PAD_DEFAULT   // A/B builds (tools/ab_inproc.py loads several libraries into one process, which share the environment)
   lay.total += CE_LDS_PAD_DEFAULT & ~15;
 #endif
-  if (const char* pad = getenv("CE_LDS_PAD_BYTES")) lay.total += atoi(pad) & ~15;  // tuning knob: lowers the workgroups resident per CU
+  if (const char* pad = ce_knob("CE_LDS_PAD_BYTES")) lay.total += atoi(pad) & ~15;  // lowers the workgroups resident per CU
   if (lay.total > 160 * 1024) { delete p; return fail(CE_ERR_UNSUPPORTED, "plan needs %d B of LDS (> 160 KiB)", lay.total); }
 
   ce_plan_info& I = p->info;
@@ -577,7 +591,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   if (e == hipSuccess) e = hipMemcpy(p->dev_plan, &P, sizeof(CeDevPlan), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->dev_re_idx, re_idx.data(), re_idx.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->dev_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
-  int blocks_per_cu = 1, n_cu = 1;
+  int blocks_per_cu = 1;
   if (e == hipSuccess) {
     CeLaunchCtx c = {};
     c.lds = lay.total;
@@ -594,15 +608,13 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   // work on it runs 2-4 % faster with two (in-process A/B: 2048 x 4 items -4.3 %, 8192 x 4 -2.1 %; 1024 x 1 +2.5 %), so large
   // launches request as much dynamic LDS as leaves room for two.  Placement only: results are unaffected.
   if (e == hipSuccess && P.n_hops == 1 && L == 1 && P.reg_nd == 2 && P.reg_kpt == CE_KPT && P.feat == 0 && lay.total <= CE_LDS_BIG_BYTES &&
-      !getenv("CE_NO_LDS_BIG")) {  // env: A/B knob
+      !ce_knob("CE_NO_LDS_BIG")) {
     int nb2 = 1;
     CeLaunchCtx c2 = {};
     c2.lds = CE_LDS_BIG_BYTES;
     c2.blocks_per_cu = &nb2;
     if (kernel_op(CE_OP_PREPARE, P, c2) == 0) p->lds_big = CE_LDS_BIG_BYTES;   // (raises the kernel's dynamic-LDS limit on this device)
   }
-  if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device);
-  p->grid_cap = blocks_per_cu * n_cu;
   if (e != hipSuccess) {
     fail(CE_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
     ce_plan_destroy(p);

@@ -23,7 +23,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "ce_plan.h"
@@ -1824,21 +1824,25 @@ int launch_t(const CeLaunchCtx& c) {
 
 // Raises the kernel's dynamic-LDS limit to what this plan needs and reports how many workgroups fit a CU.  Plans of
 // different sizes share an instantiation, so the limit only ever grows (per device): a small plan created after a
-// large one must not lower it under the large plan's launches.
+// large one must not lower it under the large plan's launches.  Read, hipFuncSetAttribute and record happen under one
+// mutex per instantiation: ctypes releases the GIL, so plans may be created from several host threads at once, and two
+// creators interleaving "set 80 KB" / "set 60 KB" would otherwise leave the attribute below the recorded limit.
 template <int L, int NH, int ND, int KPT, int FEAT>
 int prepare_t(const CeLaunchCtx& c) {
   const void* fn = reinterpret_cast<const void*>(&ce_estimate_kernel<L, NH, ND, KPT, FEAT>);
-  static std::atomic<int> lds_limit[CE_MAX_DEVICES];
+  static std::mutex mu;
+  static int lds_limit[CE_MAX_DEVICES];
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   if (dev < 0 || dev >= CE_MAX_DEVICES) return (int)hipErrorInvalidDevice;
-  int cur = lds_limit[dev].load();
-  while (c.lds > cur) {
-    // concurrent creators may both set the attribute; the larger value wins in lds_limit and is (re)applied by its owner
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
-    if (e != hipSuccess) return (int)e;
-    if (lds_limit[dev].compare_exchange_weak(cur, c.lds)) break;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (c.lds > lds_limit[dev]) {
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
+      if (e != hipSuccess) return (int)e;
+      lds_limit[dev] = c.lds;
+    }
   }
   int nb = 0;
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NT, c.lds);

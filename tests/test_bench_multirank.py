@@ -97,3 +97,35 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     out = ROOT / "gpurun_out"
     if out.is_dir():                                      # kept for profiles/ (the judge asked for the log)
         (out / "bench_rehearsal_2ranks.json").write_text(json.dumps(line) + "\n")
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_rccl_process_group():
+    """The code the driver's 8-GPU job runs and a one-GPU box otherwise never does: `init_process_group("nccl", device_id=dev)`
+    (RCCL bootstrap with this pool's IPC mode), the device-tensor `all_reduce(MAX)` of the timing, `dist.barrier()` on RCCL and
+    `destroy_process_group()` -- at world size 1 through CE_BENCH_FORCE_PG=1, launched exactly as the driver launches N > 1
+    (a fresh child `python -m torch.distributed.run`; this process never re-executes)."""
+    env = dict(os.environ, CE_BENCH_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CE_BENCH_REHEARSE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--slots", "64", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 1 and line["config"]["process_group"] == "nccl (RCCL)" and "REHEARSAL" not in line["data"]
+    assert line["config"]["global_slots"] == 64 and line["roofline"]["kernel_ms"] <= line["ms_per_step"] * 1.05
+    out = ROOT / "gpurun_out"
+    if out.is_dir():
+        (out / "bench_rccl_1rank.json").write_text(json.dumps(line) + "\n")
+
+
+def test_bench_exits_nonzero_when_the_process_group_cannot_start():
+    """A rendezvous / RCCL failure must surface as a non-zero exit with the library's message -- never a retry, never a
+    silent single-process run.  CPU-checkable part: WORLD_SIZE that contradicts --gpus is refused before anything starts."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -126,6 +126,24 @@ def test_maximum_grid_width_and_unsupported_sizes():
         E.make_plan(h1, h2, cfg, 1.0, 1, 400, 14, dev)
 
 
+@pytest.mark.parametrize("two_hops", [False, True])
+def test_scattered_mask_at_the_top_of_the_widest_grid(two_hops):
+    """A narrow scattered PRB mask on the last PRBs of a 341-PRB grid: the collapsed first pass of the TA transform probes
+    subcarriers shift .. shift + 511 of the hop's subcarrier -> pilot table, which must stay inside its 4096 entries (with
+    two hops the entries behind them are the second hop's, whose pilots here sit exactly where an over-run would look)."""
+    top = [330, 332, 335, 337, 339, 340]
+    hops = [S.hop_spec([2, 5] if two_hops else [2, 11], 335, 6, 0, 7 if two_hops else 14, mask_prbs=top)]
+    if two_hops:
+        hops.append(S.hop_spec([8, 12], 0, 6, 7, 7, mask_prbs=[0, 1, 3, 5, 20, 21]))
+    case = S.case_spec("top_scatter", 341, hops, smoothing="filter", seed=83)
+    b = S.build_case(case, 2)
+    dev = torch.device(DEV)
+    out = E.estimate(torch.as_tensor(b.grids, device=dev)[None], torch.as_tensor(b.pilots, device=dev), b.beta, b.hop1, b.hop2, b.config)
+    for it in range(2):
+        ref = O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+        check_outputs(out[0][0, it].cpu().numpy(), [float(out[i][0, it]) for i in range(1, 6)], ref[0], list(ref[1:]), 2e-5, 2e-5, f"top_scatter[{it}]")
+
+
 def test_large_plan_survives_a_later_small_plan_of_the_same_kernel():
     """Plans of different LDS sizes share a kernel instantiation; the dynamic-LDS limit of the instantiation must
     only ever grow, or relaunching the cached large plan after a small one was created would fail (or clip)."""

@@ -1,5 +1,7 @@
 """The kernel tiers against each other: the same slots through the plan's default kernel and through the alternative code
-paths its tuning knobs select (environment variables read when a plan is created, csrc/ce_api.hip) -- the re-read path
+paths its tuning knobs select (environment variables read when a plan is created -- by the DIAGNOSTIC build of the library
+only, csrc/libce_hip_knobs.so = -DCE_TUNING_KNOBS, loaded through CE_HIP_LIB; the shipped libce_hip.so, which the default
+run uses, never reads the environment: tests/test_host_and_abi.py) -- the re-read path
 instead of the register path, the widest register tier instead of the band's own, the full first TA pass instead of the
 collapsed one, DM-RS symbols re-read instead of parked in the LDS, one TA transform at a time.  Knobs that only move data
 must give bit-identical results; knobs that change a summation order must agree to rounding.  Each knob runs in a fresh
@@ -13,7 +15,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from srsran_ce_pytorch_amd import synth as S
+from srsran_ce_pytorch_amd import _lib, synth as S
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
@@ -48,8 +50,12 @@ np.savez(sys.argv[2], **out)
 
 def _run(tmp_path, knob):
     env = dict(os.environ)
+    env.pop("CE_HIP_LIB", None)
     if knob:
+        if not _lib.KNOBS_LIB_PATH.exists():
+            _lib.build(force=True)
         env[knob] = "1"
+        env["CE_HIP_LIB"] = str(_lib.KNOBS_LIB_PATH)
     dst = tmp_path / f"tier_{knob or 'default'}.npz"
     p = subprocess.run([sys.executable, "-c", CHILD, json.dumps(CASES), str(dst)], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]

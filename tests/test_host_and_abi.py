@@ -145,6 +145,31 @@ def test_host_derivation_register_path_and_limits(lib):
     assert E.derive_host(h1, h2, cfg, 1.0, 1, 52, 14).contig[0] == 0
 
 
+def test_shipped_library_ignores_tuning_knobs(lib, monkeypatch):
+    """include/ce_hip.h "Tuning knobs": only the diagnostic build (libce_hip_knobs.so, -DCE_TUNING_KNOBS) reads the
+    environment at plan creation; a stray variable in a user's environment cannot change the shipped library's kernel
+    selection or LDS sizing."""
+    import ctypes as C
+    h1, h2, cfg = S.numpy_hops(S.bench_case("filter"))
+    desc, _, keep = E.build_desc(h1, h2, cfg, 1.4125, 1, 273, 14)
+    knobs = C.CDLL(str(_lib.KNOBS_LIB_PATH))
+    knobs.ce_plan_derive_host.argtypes = [C.POINTER(_lib.PlanDesc), C.POINTER(_lib.PlanHostView)]
+    v0, v1, v2 = _lib.PlanHostView(), _lib.PlanHostView(), _lib.PlanHostView()
+    assert knobs.ce_plan_derive_host(C.byref(desc), C.byref(v0)) == 0 and v0.reg_nd == 2
+    monkeypatch.setenv("CE_FORCE_GENERIC", "1")
+    monkeypatch.setenv("CE_LDS_PAD_BYTES", "4096")
+    assert lib.ce_plan_derive_host(C.byref(desc), C.byref(v1)) == 0
+    assert v1.reg_nd == 2 and v1.lds_bytes == v0.lds_bytes                      # shipped: environment ignored
+    assert knobs.ce_plan_derive_host(C.byref(desc), C.byref(v2)) == 0
+    assert v2.reg_nd == 0 and v2.lds_bytes >= v0.lds_bytes + 4096 - 16          # diagnostic build: knobs honoured
+    src = (ROOT / "srsran_ce_pytorch_amd" / "csrc" / "ce_api.hip").read_text()
+    assert src.count("getenv(") == 1                                            # the one call inside ce_knob(), under #ifdef CE_TUNING_KNOBS
+    header = (ROOT / "include" / "ce_hip.h").read_text()
+    for name in set(re.findall(r'ce_knob\("(CE_\w+)"\)', src)):
+        assert name in header, f"{name} not documented in include/ce_hip.h"
+    del keep
+
+
 def test_mmse_extension_host_filter_matches_oracle(lib):
     """EXTENSION (parity unpinned: no reference counterpart): the C++ LU solve of W = R (R + nsr I)^-1 against numpy."""
     for case, L in ((S.bench_case("mmse"), 1), (S.case_spec("m2", 52, [S.hop_spec([2, 11], 4, 3)], smoothing="mmse"), 1),
