@@ -26,10 +26,10 @@ def pytest_configure(config):
 def golden_names(variant=None):
     names = []
     for f in sorted(GOLDEN_DIR.glob("*.npz")):
-        if variant is not None:
-            with np.load(f) as z:
-                if str(z["variant"]) != variant:
-                    continue
+        with np.load(f) as z:
+            v = str(z["variant"])
+        if v == "F" or (variant is not None and v != variant):   # "F": fuzz_ta_reference.npz, a table of reference bins, not a slot fixture
+            continue
         names.append(f.stem)
     return names
 
@@ -76,15 +76,18 @@ def ta_tie_alternatives(fx, item):
 
 
 def ta_alternatives_from(bins, powers, scs):
-    """All TA values obtained by moving, in each hop independently, the reference's bin to a neighbour whose power (in the
-    reference's own transform, `powers[h] = [below, chosen, above]`) is within TA_TIE_RATIO of the chosen bin's -- every
-    combination except "nothing moved" (two one-PRB hops can each sit on a tie: the long-form fuzzer met one)."""
+    """All TA values obtained by moving, in each hop independently, the chosen bin to a neighbour whose power (in the
+    transform the powers come from; `powers[h]` = the chosen bin's power in the MIDDLE, its neighbours at distance 1 -- and
+    2, when five values are given -- on either side, in the window of the 288 examined bins, where bins 4095 and 0 are
+    adjacent; negative = outside the window) is within TA_TIE_RATIO of the chosen bin's -- every combination except
+    "nothing moved" (two one-PRB hops can each sit on a tie: the long-form fuzzer met one)."""
     import itertools
     n_hops = len(bins)
     moves = []
     for h in range(n_hops):
-        lo, top, hi = powers[h]
-        moves.append([0] + [d for d, p in ((-1, lo), (+1, hi)) if p >= (1.0 - TA_TIE_RATIO) * top and p >= 0.0])
+        pw = [float(x) for x in powers[h]]
+        mid = len(pw) // 2
+        moves.append([0] + [d for d in range(-mid, mid + 1) if d and pw[mid + d] >= (1.0 - TA_TIE_RATIO) * pw[mid] and pw[mid + d] >= 0.0])
     alts = []
     for combo in itertools.product(*moves):
         if not any(combo):
@@ -94,6 +97,23 @@ def ta_alternatives_from(bins, powers, scs):
             ta = ta + float(bins[k] + combo[k]) / 4096.0 / float(scs)
         alts.append(ta / 2.0 if n_hops == 2 else ta)
     return alts
+
+
+_FUZZ_TA = None
+
+
+def fuzz_ta_reference(idx):
+    """The REAL reference's time alignment for case `idx` of the GPU suite's fuzz slice (tests/golden/fuzz_ta_reference.npz,
+    tools/make_fuzz_ta_reference.py): `None` where the reference has no answer (the "mmse" extension), else per item
+    `(ta_seconds, bins[hop], powers[hop][5])` -- the reference's own arg-max bins and its own IFFT powers around them."""
+    global _FUZZ_TA
+    if _FUZZ_TA is None:
+        with np.load(GOLDEN_DIR / "fuzz_ta_reference.npz") as z:
+            _FUZZ_TA = {k: z[k] for k in ("ta_bin", "ta_pw", "ta_ref", "valid")}
+    z = _FUZZ_TA
+    if not z["valid"][idx]:
+        return None
+    return [(float(z["ta_ref"][idx, it]), [int(x) for x in z["ta_bin"][idx, it]], z["ta_pw"][idx, it].astype(np.float64)) for it in range(2)]
 
 
 def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what="", ta_alternatives=(), tol_rsrp=None):

@@ -77,11 +77,13 @@ def realize(case, extras, n_items=2):
     return b
 
 
-def compare_item(case, b, got_ch, got_sc, ref, stages, what):
+def compare_item(case, b, got_ch, got_sc, ref, stages, what, ta_ref=None):
     """The suite's protocol (conftest.check_outputs) plus what random narrow bands need: a TA neighbour bin the ORACLE's
     own transform puts within TA_TIE_RATIO of its arg-max is accepted (one bin per hop); 1-2 pilots give a flat /
     periodic |IFFT| whose arg-max is arbitrary on every side; the CFO has a float32 floor of ~3e-7 rad whatever the
-    angle; "mean" smoothing can cancel to a small band mean, so its rounding scales with |H| ~ 1, not with the result."""
+    angle; "mean" smoothing can cancel to a small band mean, so its rounding scales with |H| ~ 1, not with the result.
+    `ta_ref` = `(seconds, bins[hop], powers[hop][5])` from the REAL reference (conftest.fuzz_ta_reference): the TA
+    expectation and the tie alternatives then come from the reference's own transform, the oracle's are not consulted."""
     n_pil, n_hops, scs = b.pilots.shape[0], len(case["hops"]), case["scs"]
     rs = [ref[1], ref[2], ref[3], ref[4], np.nan if ref[5] is None else ref[5]]
     got = list(got_sc)
@@ -101,6 +103,9 @@ def compare_item(case, b, got_ch, got_sc, ref, stages, what):
         tb = float(got[3]) * 4096.0 * scs * (2.0 if n_hops == 2 else 1.0)
         assert abs(tb - round(tb)) < 1e-6 and -144 * n_hops <= round(tb) <= 143 * n_hops, f"{what}: TA {got[3]!r} is not a sum of examined bins"
         got[3] = rs[3]
+    elif ta_ref is not None:
+        rs[3] = ta_ref[0]
+        alts = ta_alternatives_from(ta_ref[1][:n_hops], ta_ref[2][:n_hops], scs)
     else:
         alts = ta_alternatives_from([st["ta_bin"] for st in stages], [st["ta_pw"] for st in stages], scs)
     if np.isfinite(rs[4]) and abs(got[4] - rs[4]) <= 5e-8 * scs:

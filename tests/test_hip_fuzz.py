@@ -1,12 +1,18 @@
 """A bounded, deterministic slice of the differential fuzzer in the GPU suite: N_CASES seeded random geometries (see
 fuzz_cases.py for what is drawn) through the HIP estimator and the CPU oracle, compared with the suite's protocol; where
-the oracle raises, the HIP boundary must raise the same exception class.  No input class is skipped."""
+the oracle raises, the HIP boundary must raise the same exception class.  No input class is skipped.
+
+The time alignment -- index work, decided by the reference's own complex64 IFFT -- is NOT taken from the oracle: the expected
+value and the near-tie alternatives of every case the reference can run come from tests/golden/fuzz_ta_reference.npz
+(the real ce_rule_tensorized / ce_dl_cnn run on these very cases, tools/make_fuzz_ta_reference.py); only the "mmse"
+extension, which the reference lacks, falls back to the oracle's transform."""
 import numpy as np
 import pytest
 import torch
 
 import ce_oracle as O
 import fuzz_cases as F
+from conftest import fuzz_ta_reference
 from srsran_ce_pytorch_amd import estimator as E
 
 pytestmark = pytest.mark.gpu
@@ -38,7 +44,7 @@ LOGGED_CASES = [
 
 @pytest.mark.parametrize("k", range(len(LOGGED_CASES)))
 def test_logged_fuzz_case(k):
-    _run_case(LOGGED_CASES[k]["case"], LOGGED_CASES[k]["extras"], f"logged{k}")
+    _run_case(LOGGED_CASES[k]["case"], LOGGED_CASES[k]["extras"], N_CASES + k)   # (their rows of the reference file follow the seeded ones)
 
 
 def _run_case(case, extras, idx):
@@ -73,6 +79,8 @@ def _run_case(case, extras, idx):
     assert werr is None, f"the oracle raised {werr!r}, HIP did not :: {case} {extras}"
     ch = out[0][0].cpu().numpy()
     sc = [t[0].cpu().numpy() if t.numel() else None for t in out[1:]]
+    ta_ref = fuzz_ta_reference(idx)
+    assert (ta_ref is None) == (case["smoothing"] == "mmse"), "the reference pins every case but the mmse extension's"
     for it in range(2):
         got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], np.nan if sc[4] is None else sc[4][it]]
-        F.compare_item(case, b, ch[it], got, want[it], stages[it], f"fuzz[{idx}][{it}] {case} {extras}")
+        F.compare_item(case, b, ch[it], got, want[it], stages[it], f"fuzz[{idx}][{it}] {case} {extras}", None if ta_ref is None else ta_ref[it])

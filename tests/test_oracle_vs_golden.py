@@ -52,3 +52,29 @@ def test_error_conventions():
     fx.config.Smoothing = "bogus"
     with pytest.raises(ValueError):
         O.srs_channel_estimator(fx.grids[0], fx.pilots, fx.beta, fx.hop1, fx.hop2, fx.config)
+
+
+def test_oracle_time_alignment_against_the_reference_on_the_fuzz_slice():
+    """tests/golden/fuzz_ta_reference.npz holds the REAL reference's arg-max bins and IFFT powers for the GPU suite's fuzz
+    cases (tools/make_fuzz_ta_reference.py).  A sample of them on the CPU: the numpy oracle, put through the same protocol the
+    HIP path is held to, must match the reference's TA or sit on a neighbour the reference's own transform puts within
+    TA_TIE_RATIO of its maximum."""
+    import fuzz_cases as F
+    import test_hip_fuzz as TF
+    from conftest import fuzz_ta_reference
+
+    checked = 0
+    for idx in range(0, TF.N_CASES, 9):
+        case, extras = F.draw(np.random.default_rng([TF.BASE_SEED, idx]), 273 if idx % 8 == 0 else 106)
+        tr = fuzz_ta_reference(idx)
+        assert (tr is None) == (case["smoothing"] == "mmse")
+        if tr is None:
+            continue
+        b = F.realize(case, extras)
+        for it in range(2):
+            st = []
+            ref = O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp=extras["interp"], stages=st)
+            got = [ref[1], ref[2], ref[3], ref[4], np.nan if ref[5] is None else ref[5]]
+            F.compare_item(case, b, ref[0], got, ref, st, f"fuzz[{idx}][{it}]", tr[it])
+            checked += 1
+    assert checked >= 60
