@@ -136,6 +136,16 @@ def cpu_baseline(case, n_ports, target_core_seconds=20.0, interp="linear", denoi
     return out
 
 
+def kernel_source_sha():
+    """Hash of the sources the estimation kernels are built from (same recipe as tools/distill_round.py)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("ce_estimate_kernel.h", "ce_plan.h", "ce_api.hip", "ce_inst.inc"):
+        h.update((ROOT / "srsran_ce_pytorch_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def time_steps(step, barrier, steps, warmup, make_events=None):
     """The driver's timing contract for one rank: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by
     `barrier()` (process-group barrier + device synchronise) on both sides.  Returns (wall seconds of the bracket,
@@ -316,12 +326,18 @@ def main():
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     value = aggregate_slots_per_second(n_slots, args.steps, elapsed, world)
     # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the
-    # MI355X guide prescribes for gfx950); collected once per round and committed under profiles/
-    traffic, traffic_src = None, None
+    # MI355X guide prescribes for gfx950); collected once per round and committed under profiles/ together with the git
+    # head and a hash of the kernel sources it was taken at.  A profile of OTHER kernel sources than the ones this run
+    # was built from says nothing about this run: `traffic` is then null (and `traffic_stale` says why).
+    traffic, traffic_src, traffic_head, traffic_stale = None, None, None, None
     for prof in sorted((ROOT / "profiles").glob("round*_summary.json"), reverse=True):   # newest round first
         pj = json.loads(prof.read_text())
         if pj.get("workload", "").startswith(args.workload) and n_slots == wl["slots"] and "hbm_traffic_bytes_per_launch" in pj:
-            traffic, traffic_src = pj["hbm_traffic_bytes_per_launch"], f"profiles/{prof.name}"
+            traffic_src, traffic_head = f"profiles/{prof.name}", pj.get("head")
+            if pj.get("kernel_source_sha16") == kernel_source_sha():
+                traffic = pj["hbm_traffic_bytes_per_launch"]
+            else:
+                traffic_stale = "kernel sources changed since the profile was taken"
             break
     line = {
         "metric": "slots/sec (273-PRB PUSCH, 4 Rx)" if n_ports == 4 else f"slots/sec (273-PRB PUSCH, {n_ports} Rx)",
@@ -333,7 +349,8 @@ def main():
                    "global_slots": world * n_slots, "rx_layout": "[slot][port][sym][sc]", "parallelism": f"slot-shard x{world}, no collective",
                    "process_group": ("gloo (rehearsal)" if rehearse else "nccl (RCCL)") if use_pg else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_head": traffic_head,
+                     **({"traffic_stale": traffic_stale} if traffic_stale else {}), "lds_bytes_per_workgroup": plan.lds_bytes,
                      "kernel": "ce_estimate_kernel<1,1,2,7,%d>" % (1 if wl["smoothing"] == "filter" else 3 if wl["smoothing"] == "mmse" else 0), "kernel_ms": kernel_ms,
                      "alg_bytes_per_slot": bytes_per_slot, "alg_bytes_per_launch": bytes_per_launch},
     }

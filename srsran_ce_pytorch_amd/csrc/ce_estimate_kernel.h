@@ -676,6 +676,74 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
   }
 }
 
+// The same writer for two hops whose fill rectangles SHARE symbols (the reference harness describes both hops of a hopping
+// allocation with the slot's whole symbol range, scripts/validation/validate_case4.py:85-103; hop 2 overwrites hop 1 where
+// they also share PRBs, T:872-896).  The hop of an element is then "the last hop whose symbol AND PRB range cover it": the
+// symbol half is a constant of the phase-owning thread (`cand`: bit h = hop h's symbols cover this thread's symbol), the PRB
+// half is one range compare per hop on the PRB index the thread tracks anyway.  Both hops carry the same DM-RS RE mask (the
+// host refuses anything else, T:869), so the interpolation weight, the anchor ordinal inside the PRB and the "at / after the
+// last pilot of the PRB" test are hop-independent thread constants; only the P row, the PRB origin and the PRB count are
+// selected per element.  Branch-free body (selects), so unrolled iterations keep their LDS reads in flight together.
+template <int L>
+__device__ __forceinline__ void write_grid_direct_ovl(const CeDevPlan* __restrict__ plan, const float2* P, const float2* tab,
+                                                      const float2* rot_final, float4* out4, int n_re, int n_re_pad, int tid) {
+  constexpr int ROW4 = 7 * L, ACTIVE = (NT / 252) * 252, SC_STEP = ACTIVE / ROW4, QS = SC_STEP / 12;
+  static_assert(SC_STEP % 12 == 0, "direct form needs whole-PRB steps");
+  const int ph = tid % ROW4, sc_lane = tid / ROW4, r12 = sc_lane % 12;
+  const CeDevHop& h0 = plan->hop[0];
+  const CeDevHop& h1 = plan->hop[1];
+  const int p0a = h0.prb_start, n0 = h0.n_prbs, p1a = h1.prb_start, n1 = h1.n_prbs;
+  float2 rsel[2];
+  float al[2];
+  int ord[2], dppe[2], lrow[2];
+  unsigned cand[2];
+  bool tail_r[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int rem = 2 * ph + e, sym = rem / L, l = rem - sym * L, c = l >> 1;
+    cand[e] = (sym >= h0.sym0 && sym < h0.sym1 ? 1u : 0u) | (sym >= h1.sym0 && sym < h1.sym1 ? 2u : 0u);
+    rsel[e] = cand[e] ? rot_final[sym] : make_float2(0.f, 0.f);   // rot_final == 1 when no CFO ramp applies
+    const float2 t = tab[c * 12 + r12];                           // hop 0's anchors = hop 1's (same RE mask)
+    al[e] = t.x;
+    ord[e] = __float_as_int(t.y);
+    dppe[e] = h0.dpp[c];
+    lrow[e] = l * n_re_pad;
+    tail_r[e] = 12 * (n0 - 1) + r12 >= h0.last_idx[c];
+  }
+  const bool same = L == 1 && cand[0] == cand[1];                 // one layer: both elements are the same subcarrier of the same row
+  if (tid < ACTIVE) {
+    float4* o = out4 + tid;
+    const int n_iter = (plan->n_sc - sc_lane + SC_STEP - 1) / SC_STEP;
+    int qabs = sc_lane / 12;
+#pragma unroll 2
+    for (int it = 0; it < n_iter; ++it) {
+      const bool in0 = (unsigned)(qabs - p0a) < (unsigned)n0, in1 = (unsigned)(qabs - p1a) < (unsigned)n1;
+      float2 y[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (e == 1 && same) {
+          y[1] = y[0];
+        } else {
+          const bool use1 = in1 && (cand[e] & 2u), use0 = !use1 && in0 && (cand[e] & 1u), valid = use1 || use0;
+          const int q = qabs - (use1 ? p1a : p0a), np = use1 ? n1 : n0;
+          int hi = q * dppe[e] + ord[e], lo = hi - 1;
+          if (q == np - 1 && tail_r[e]) lo = hi = n_re - 1;       // at/after the last pilot: hold (T:316,321)
+          lo = lo < 0 ? 0 : lo;                                    // at/before the first pilot: hold (T:315,320)
+          if (!valid) lo = hi = 0;
+          const float2* Pe = P + (use1 ? L * n_re_pad : 0) + lrow[e];
+          const float2 u = Pe[lo], v = Pe[hi];
+          const float2 w = make_float2(u.x + al[e] * (v.x - u.x), u.y + al[e] * (v.y - u.y));
+          y[e] = make_float2(valid ? w.x : 0.f, valid ? w.y : 0.f);
+        }
+      }
+      const float2 ya = cmul(y[0], rsel[0]), yb = cmul(y[1], rsel[1]);
+      store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
+      o += ACTIVE;
+      qabs += QS;
+    }
+  }
+}
+
 // L layers, NH hops; ND = DM-RS symbols per hop whose pilot REs (and pilots) stay in registers between the CFO,
 // LS and residual stages (one layer, n_re <= KPT*NT); ND = 0 re-reads them from global memory
 // (L2) in each of the three stages and works for any geometry.
@@ -1668,8 +1736,10 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   }
 
   if ((CE_ABLATE & 8) || rowwise) {
-  } else if (n_sym == CE_MAX_SYMBOLS && !lp->sym_overlap) {
-    // Fast writer (hop of an element decided by its symbol alone).  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
+  } else if (n_sym == CE_MAX_SYMBOLS) {
+    // Fast writer.  The hop of an element is decided by its symbol alone -- or, for two hops whose fill rectangles share
+    // symbols (plan: sym_overlap; the harness's own two-hop convention), by its symbol AND its subcarrier: the last hop
+    // whose symbol range (thread constant `cand`) and band cover it (T:872-896).  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
     // each of ACTIVE (a multiple of 252) threads owns ONE (symbol, layer) float4 phase for the whole item:
     // its two rotation phasors and hop/layer selection live in registers, and a workgroup iteration
     // stores ACTIVE*16 contiguous bytes.  The interpolated, un-rotated response H[hop][layer][sc] is staged in the LDS
@@ -1681,18 +1751,24 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
     const int ph = tid % ROW4, sc_lane = tid / ROW4;
     int hsel[2], lsel[2];
     float2 rsel[2];
+    unsigned cand[2];   // bit h: hop h's symbols cover this thread's symbol
+    const bool ovl = NH == 2 && lp->sym_overlap;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int rem = 2 * ph + e, sym = rem / L;
       lsel[e] = rem - sym * L;
       int h = -1;
+      cand[e] = 0u;
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh)
-        if (sym >= lp->hop[hh].sym0 && sym < lp->hop[hh].sym1) h = hh;  // a later hop overwrites (T:872-896)
+        if (sym >= lp->hop[hh].sym0 && sym < lp->hop[hh].sym1) { h = hh; cand[e] |= 1u << hh; }  // a later hop overwrites (T:872-896)
       hsel[e] = h < 0 ? 0 : h;
       rsel[e] = h < 0 ? make_float2(0.f, 0.f) : rot_final[sym];  // rot_final == 1 when no CFO ramp applies
     }
     float4* out4 = reinterpret_cast<float4*>(out);
+    // sym_overlap: subcarrier ranges of the two hops; element e at subcarrier s takes hop 1 where (cand[e] & 2) and s is in
+    // hop 1's band, else hop 0 where (cand[e] & 1) and s is in hop 0's band, else zero
+    const int ob0 = lp->hop[0].sc0, on0 = lp->hop[0].n_sc_hop, ob1 = lp->hop[NH - 1].sc0, on1 = lp->hop[NH - 1].n_sc_hop;
     if (cnn_iterated) {
       // the in-painted rows (staged above) through the same phase-owning store loop; zeros outside a hop's band
       const int hs = lp->cnn_h_stride, n_sc = lp->n_sc;
@@ -1700,7 +1776,26 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       const float2* HB = scratch + (hsel[1] * L + lsel[1]) * hs;
       const int a0 = lp->hop[hsel[0]].sc0, an = lp->hop[hsel[0]].n_sc_hop;
       const int b0 = lp->hop[hsel[1]].sc0, bn = lp->hop[hsel[1]].n_sc_hop;
-      if (tid < ACTIVE) {
+      if (ovl) {
+        if (tid < ACTIVE) {
+          float4* o = out4 + tid;
+          const float2* R0a = scratch + lsel[0] * hs;
+          const float2* R1a = scratch + (L + lsel[0]) * hs;
+          const float2* R0b = scratch + lsel[1] * hs;
+          const float2* R1b = scratch + (L + lsel[1]) * hs;
+#pragma unroll 2
+          for (int s = sc_lane; s < n_sc; s += SC_STEP) {
+            const bool in0 = (unsigned)(s - ob0) < (unsigned)on0, in1 = (unsigned)(s - ob1) < (unsigned)on1;
+            const float2 a0v = R0a[in0 ? s - ob0 : 0], a1v = R1a[in1 ? s - ob1 : 0], b0v = R0b[in0 ? s - ob0 : 0], b1v = R1b[in1 ? s - ob1 : 0];
+            const bool ua1 = in1 && (cand[0] & 2u), ua0 = !ua1 && in0 && (cand[0] & 1u);
+            const bool ub1 = in1 && (cand[1] & 2u), ub0 = !ub1 && in0 && (cand[1] & 1u);
+            const float2 za = ua1 ? a1v : ua0 ? a0v : make_float2(0.f, 0.f), zb = ub1 ? b1v : ub0 ? b0v : make_float2(0.f, 0.f);
+            const float2 ya = cmul(za, rsel[0]), yb = cmul(zb, rsel[1]);
+            store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
+            o += ACTIVE;
+          }
+        }
+      } else if (tid < ACTIVE) {
         float4* o = out4 + tid;
 #pragma unroll 4
         for (int s = sc_lane; s < n_sc; s += SC_STEP) {
@@ -1712,6 +1807,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
           o += ACTIVE;
         }
       }
+    } else if (direct_ok<SC_STEP>() && lp->interp != CE_INTERP_CNN && ovl) {
+      if constexpr (direct_ok<SC_STEP>() && NH == 2) write_grid_direct_ovl<L>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);
     } else if (direct_ok<SC_STEP>() && lp->interp != CE_INTERP_CNN) {
       if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH, (ce_min_waves(NH, ND, KPT, FEAT, L) >= 5 ? 2 : ce_min_waves(NH, ND, KPT, FEAT, L) == 2 ? CE_WR_WIDE : CE_WR_UNROLL)>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);  // (the 96-VGPR tiers have no room for four iterations' operands; 0 = per-element branches: measured 2-4 % faster where only two workgroups share a CU)
     } else if (!(CE_LEAN == 1 && direct_ok<SC_STEP>())) {
@@ -1732,7 +1829,26 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
           }
         }
         __syncthreads();
-        if (tid < ACTIVE) {
+        if (ovl) {
+          // rows of both hops are staged (zeros outside a hop's own band): the later hop wins where its band covers the subcarrier
+          if (tid < ACTIVE) {
+            float4* o = out4 + (int64_t)c0 * ROW4 + tid;
+            const float2* R0a = scratch + (lsel[0] << ch_log2);
+            const float2* R1a = scratch + ((L + lsel[0]) << ch_log2);
+            const float2* R0b = scratch + (lsel[1] << ch_log2);
+            const float2* R1b = scratch + ((L + lsel[1]) << ch_log2);
+#pragma unroll 2
+            for (int s = sc_lane; s < cn; s += SC_STEP) {
+              const bool in1 = (unsigned)(c0 + s - ob1) < (unsigned)on1;
+              const float2 a0v = R0a[s], a1v = R1a[s], b0v = R0b[s], b1v = R1b[s];
+              const float2 za = (in1 && (cand[0] & 2u)) ? a1v : (cand[0] & 1u) ? a0v : make_float2(0.f, 0.f);
+              const float2 zb = (in1 && (cand[1] & 2u)) ? b1v : (cand[1] & 1u) ? b0v : make_float2(0.f, 0.f);
+              const float2 ya = cmul(za, rsel[0]), yb = cmul(zb, rsel[1]);
+              store_f4(o, make_float4(ya.x, ya.y, yb.x, yb.y));
+              o += ACTIVE;
+            }
+          }
+        } else if (tid < ACTIVE) {
           float4* o = out4 + (int64_t)c0 * ROW4 + tid;
 #pragma unroll 4
           for (int s = sc_lane; s < cn; s += SC_STEP) {
@@ -1746,8 +1862,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       }
     }
   } else if (!CE_LEAN) {
-    // generic writer (any n_sym, hops that share symbols -- the harness's own two-hop convention,
-    // scripts/validation/validate_case4.py:85-103 -- for either interpolator): decode (subcarrier, symbol, layer) per
+    // generic writer (grids with fewer than 14 symbols, for either interpolator): decode (subcarrier, symbol, layer) per
     // element; where the hops' rectangles overlap the later hop wins (T:872-896, src/ce_dl_cnn.py:233-352)
     auto elem = [&](int sc, int rem) -> float2 {
       const int sym = rem / L, l = rem - sym * L;

@@ -48,7 +48,7 @@ def main():
         rx, pil = S.torch_inputs(case, a.slots, a.ports, dev, 1)
         plans, outs = {}, {}
         for n, E in pk.items():
-            plans[n] = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], 14, dev, interp)
+            plans[n] = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], case["n_sym"], dev, interp)
             outs[n] = E.estimate_with_plan(plans[n], rx, pil) if not outs else None
         out = next(o for o in outs.values() if o is not None)
         t = {n: [] for n in names}

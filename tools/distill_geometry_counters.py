@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r2_geo_{trace,fetch,write,sq}/ (rocprofv3 runs of tools/prof_geometries.py) -> profiles/<tag>_geometry_counters.json.
+"""gpurun_out/<prefix>_geo_{trace,fetch,write,sq}/ (rocprofv3 runs of tools/prof_geometries.py) -> profiles/<tag>_geometry_counters.json.
 
 Passes (each its own rocprofv3 run; --pmc never combined with tracing):
   trace  rocprofv3 --kernel-trace --stats --output-format csv
@@ -8,7 +8,8 @@ Passes (each its own rocprofv3 run; --pmc never combined with tracing):
   sq     rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 Dispatches of ce_estimate_kernel are attributed to geometries by order (gpurun_out/prof_geometries_order.json)."""
 import csv, glob, json, os, statistics as st, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round3"
+PFX = sys.argv[2] if len(sys.argv) > 2 else "r3"
 OUT = "gpurun_out/distilled"   # gpurun merges only gpurun_out/ back; copy the files into profiles/ afterwards
 os.makedirs(OUT, exist_ok=True)
 order = json.load(open("gpurun_out/prof_geometries_order.json"))
@@ -33,7 +34,7 @@ def per_geometry(rows, field="Counter_Value"):
 
 
 res = [dict(o) for o in order]
-tr = list(csv.DictReader(open(newest("gpurun_out/r2_geo_trace/*/*_kernel_trace.csv"))))
+tr = list(csv.DictReader(open(newest(f"gpurun_out/{PFX}_geo_trace/*/*_kernel_trace.csv"))))
 tr = [r for r in tr if "ce_estimate" in r["Kernel_Name"]]
 tr.sort(key=lambda r: int(r["Dispatch_Id"]))
 i = 0
@@ -45,7 +46,7 @@ for r_, o in zip(res, order):
     r_["kernel_us_median"] = st.median(durs) / 1e3
     r_["alg_GBps"] = o["alg_bytes_per_launch"] / (st.median(durs) * 1e-9) / 1e9
     r_["alg_frac_of_8TBps"] = r_["alg_GBps"] / 8000.0
-for name, d, scale in (("FETCH_SIZE", "r2_geo_fetch", 1024 * 2), ("WRITE_SIZE", "r2_geo_write", 1024)):
+for name, d, scale in (("FETCH_SIZE", f"{PFX}_geo_fetch", 1024 * 2), ("WRITE_SIZE", f"{PFX}_geo_write", 1024)):
     for r_, v in zip(res, per_geometry(dispatches(d, name))):
         r_[("hbm_read_bytes" if name == "FETCH_SIZE" else "hbm_write_bytes")] = v * scale
 for r_ in res:
@@ -55,7 +56,7 @@ for r_ in res:
 sqn = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]
 for c in sqn:
     try:
-        for r_, v in zip(res, per_geometry(dispatches("r2_geo_sq", c))):
+        for r_, v in zip(res, per_geometry(dispatches(f"{PFX}_geo_sq", c))):
             r_[c] = v
     except Exception as e:
         print("missing", c, e)

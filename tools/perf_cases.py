@@ -35,4 +35,18 @@ CASES = [
     ("L1 3dmrs 150 PRB in 273", CS("d3w", 273, [H([2, 7, 11], 60, 150)]), "linear"),
     ("L1 2dmrs 160 PRB in 273", CS("d2w", 273, [H([2, 11], 60, 160)]), "linear"),
     ("L1 3dmrs 70 PRB in 106", CS("d3m", 106, [H([2, 7, 11], 30, 70)]), "linear"),
+    # the shapes the reference's own harness runs (52-PRB grids, ~3-PRB allocations, scripts/validation/validate_case{0,4,8}.py):
+    # case 0 = 3 PRB at PRB 40, DM-RS symbols 0/4/8/12; case 4 = two hops of 3 PRB, BOTH described with the slot's whole symbol
+    # range (validate_case4.py:85-103) -> hops whose fill rectangles share symbols; case 8 = two layers; + the same two-hop
+    # convention at full band, the disjoint-symbol rows to compare with, and a 12-symbol grid (element-wise writer)
+    ("harness case0: 3 PRB @40, 4dmrs, 52 grid", CS("hc0", 52, [H([0, 4, 8, 12], 40, 3)], scs=15e3), "linear"),
+    ("harness case4: 2 hops x 3 PRB, full-slot hops", CS("hc4", 52, [H([0, 4], 3, 3, 0, 14), H([8, 12], 28, 3, 0, 14)], scs=15e3), "linear"),
+    ("... same hops, disjoint symbols", CS("hc4d", 52, [H([0, 4], 3, 3, 0, 7), H([8, 12], 28, 3, 7, 7)], scs=15e3), "linear"),
+    ("harness case8-like: L2 3 PRB 4dmrs", CS("hc8", 52, [H([0, 4, 8, 12], 40, 3)], n_layers=2, scs=15e3), "linear"),
+    ("L2 2 hops x 3 PRB, full-slot hops", CS("hc4l2", 52, [H([0, 4], 3, 3, 0, 14), H([8, 12], 28, 3, 0, 14)], n_layers=2, scs=15e3), "linear"),
+    ("L1 2 hops x 2dmrs 136 PRB, full-slot hops", CS("h2fs", 273, [H([1, 5], 0, 136, 0, 14), H([8, 12], 137, 136, 0, 14)]), "linear"),
+    ("L1 2 hops x 1dmrs 12 PRB in 52, full-slot hops", CS("h2tfs", 52, [H([2], 3, 12, 0, 14), H([9], 30, 12, 0, 14)]), "linear"),
+    ("L1 cnn 2 hops x 3 PRB, full-slot hops", CS("hc4c", 52, [H([0, 4], 3, 3, 0, 14), H([8, 12], 28, 3, 0, 14)], scs=15e3), "cnn"),
+    ("L1 25 PRB in 52, 12-symbol grid", CS("s12", 52, [H([2], 10, 25, 0, 12)], n_sym=12), "linear"),
+    ("L1 273 PRB, 12-symbol grid", CS("w12", 273, [H([2], 0, 273, 0, 12)], n_sym=12), "linear"),
 ]

@@ -16,7 +16,7 @@ for name, case, interp in cases:
         continue
     h1, h2, cfg = S.numpy_hops(case)
     L = case["n_layers"]
-    plan = E.make_plan(h1, h2, cfg, case["beta"], L, case["n_prb_grid"], 14, dev, interp)
+    plan = E.make_plan(h1, h2, cfg, case["beta"], L, case["n_prb_grid"], case["n_sym"], dev, interp)
     rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
     out = E.estimate_with_plan(plan, rx, pil)
     torch.cuda.synchronize()

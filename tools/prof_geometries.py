@@ -26,7 +26,7 @@ by_name = {n: (c, i) for n, c, i in CASES}
 
 def run(tag, case, interp, slots, ports, ref_layout=False):
     h1, h2, cfg = S.numpy_hops(case)
-    plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], 14, dev, interp)
+    plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], case["n_sym"], dev, interp)
     rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
     if ref_layout:
         rx = rx.contiguous()

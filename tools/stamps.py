@@ -36,7 +36,7 @@ for name, case, interp in CASES:
         continue
     for slots, ports in sizes:
         h1, h2, cfg = S.numpy_hops(case)
-        plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], 14, dev, interp)
+        plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], case["n_sym"], dev, interp)
         rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
         n = slots * ports
         st = torch.zeros((n, 16), dtype=torch.int64, device=dev)
