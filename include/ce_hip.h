@@ -97,7 +97,8 @@ typedef struct ce_plan_info {
 /* What ce_plan_create derives on the host, for inspection and CPU-only tests. */
 typedef struct ce_plan_host_view {
   int32_t n_re, n_dmrs_total, n_pils, rc_len;   /* n_pils, len(rcFilter): T:638-647 */
-  int32_t reg_nd, lds_bytes, scratch_bytes, filt_windowed, cfo_estimated, reserved;
+  int32_t reg_nd, lds_bytes, scratch_bytes, filt_windowed, cfo_estimated;
+  int32_t narrow;                                /* 1: the plan runs on the wave-per-item kernel for narrow allocations */
   int32_t ta_nres[CE_MAX_HOPS], contig[CE_MAX_HOPS];
   int32_t last_idx[CE_MAX_HOPS][CE_MAX_CDM];     /* last pilot RE of the hop band (T:314) */
   int32_t r_ord[CE_MAX_HOPS][CE_MAX_CDM][12];    /* right-anchor ordinal inside the PRB per RE (T:325) */
@@ -173,6 +174,7 @@ int ce_time_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[
  *   CE_CNN_GENERAL     ce_dl_cnn in-painting always iterated (no closed forms)
  *   CE_LDS_PAD_BYTES   extra dynamic LDS per workgroup (lowers the workgroups resident per CU)
  *   CE_NO_LDS_BIG      no 80 KB LDS request for large launches of the wide none / mean kernel
+ *   CE_NO_NARROW       narrow allocations on the workgroup-per-item kernels instead of the wave-per-item kernel
  * Knobs are not part of the host-side plan-cache key: set them before the process creates its first plan.
  */
 const char* ce_last_error(void);

@@ -22,8 +22,8 @@ KNOBS_LIB_PATH = CSRC / "libce_hip_knobs.so"
 # the estimation kernel template (ce_estimate_kernel.h) is instantiated in slices, one translation unit each, so the
 # units compile concurrently (ce_inst.inc)
 SOURCES = ["ce_api.hip", "ce_denoise.hip", "ce_inst_reg_h1_f0.hip", "ce_inst_reg_h1_f1.hip", "ce_inst_reg_h1_f1w.hip", "ce_inst_reg_h2_f0.hip",
-           "ce_inst_reg_h2_f1.hip", "ce_inst_gen_h1.hip", "ce_inst_gen_h2.hip"]
-HEADERS = ["ce_plan.h", "ce_estimate_kernel.h", "ce_inst.inc"]
+           "ce_inst_reg_h2_f1.hip", "ce_inst_gen_h1.hip", "ce_inst_gen_h2.hip", "ce_inst_narrow.hip"]
+HEADERS = ["ce_plan.h", "ce_estimate_kernel.h", "ce_narrow_kernel.h", "ce_inst.inc"]
 
 CE_ABI_VERSION = 2
 CE_MAX_CDM, CE_MAX_HOPS, CE_MAX_SYMBOLS = 2, 2, 14
@@ -56,7 +56,7 @@ class PlanInfo(C.Structure):
 class PlanHostView(C.Structure):
     _fields_ = [("n_re", C.c_int32), ("n_dmrs_total", C.c_int32), ("n_pils", C.c_int32), ("rc_len", C.c_int32),
                 ("reg_nd", C.c_int32), ("lds_bytes", C.c_int32), ("scratch_bytes", C.c_int32), ("filt_windowed", C.c_int32),
-                ("cfo_estimated", C.c_int32), ("reserved", C.c_int32),
+                ("cfo_estimated", C.c_int32), ("narrow", C.c_int32),
                 ("ta_nres", C.c_int32 * CE_MAX_HOPS), ("contig", C.c_int32 * CE_MAX_HOPS),
                 ("last_idx", (C.c_int32 * CE_MAX_CDM) * CE_MAX_HOPS),
                 ("r_ord", ((C.c_int32 * 12) * CE_MAX_CDM) * CE_MAX_HOPS),

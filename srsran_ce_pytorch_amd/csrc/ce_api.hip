@@ -160,6 +160,7 @@ bool mmse_matrix(const uint16_t* sc, int m, double scs, double tau, double nsr, 
 
 // Routes a launch / prepare to the translation unit holding the plan's instantiation (ce_inst_*.hip).
 static int kernel_op(int op, const CeDevPlan& P, const CeLaunchCtx& c) {
+  if (P.narrow) return ce_tu_narrow(op, P.n_layers * 10 + P.n_hops, c);
   const int key = CE_KERNEL_KEY(P.feat, P.n_layers, P.reg_nd, P.reg_kpt);
   const bool two = P.n_hops == 2;
   if (P.reg_nd == 0 || P.feat == 3) return two ? ce_tu_gen_h2(op, key, c) : ce_tu_gen_h1(op, key, c);
@@ -548,7 +549,26 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       }
     }
   }
+  // Narrow allocations run on the wave-per-item kernel (ce_narrow_kernel.h): four items per workgroup, one wave each.
+  // What it covers: linear interpolation, none / mean / filter, 14-symbol grids, at most CE_NARROW_MAX_RE pilots per symbol,
+  // every hop's band inside the collapsed time-alignment window (ta_win: scattered PRB masks may span more), and a
+  // workgroup's LDS (plan + twiddles + 4 x {staged hop, P, tables}) within CE_NARROW_LDS_LIMIT.  Everything else -- and
+  // every plan when the diagnostic build sees CE_NO_NARROW -- takes the workgroup-per-item kernels.
+  {
+    int nd_max = 0;
+    bool win_ok = true;
+    for (int h = 0; h < d->n_hops; ++h) {
+      nd_max = std::max(nd_max, (int)P.hop[h].n_dmrs);
+      win_ok = win_ok && P.hop[h].ta_win != 0u;
+    }
+    P.nrw_nd_max = nd_max;
+    P.nrw_magic_nre = (uint32_t)(0x100000000ull / (unsigned)n_re) + 1u;
+    const CeNarrowLayout nl = ce_narrow_layout(P.n_hops, L, nd_max, P.n_re_pad);
+    P.narrow = (d->interp == CE_INTERP_LINEAR && d->smoothing != CE_SMOOTH_MMSE && d->n_sym == CE_MAX_SYMBOLS && n_re <= CE_NARROW_MAX_RE &&
+                n_re >= CE_NARROW_MIN_RE && win_ok && nl.total <= CE_NARROW_LDS_LIMIT && !ce_knob("CE_NO_NARROW")) ? 1 : 0;
+  }
   CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
+  if (P.narrow) lay.total = ce_narrow_layout(P.n_hops, L, P.nrw_nd_max, P.n_re_pad).total;
 #ifdef CE_LDS_PAD_DEFAULT   // A/B builds (tools/ab_inproc.py loads several libraries into one process, which share the environment)
   lay.total += CE_LDS_PAD_DEFAULT & ~15;
 #endif
@@ -598,7 +618,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     c.blocks_per_cu = &blocks_per_cu;
     const int kr = kernel_op(CE_OP_PREPARE, P, c);
     if (kr < 0) {
-      fail(CE_ERR_UNSUPPORTED, "no kernel for (layers %d, hops %d, reg_nd %d, kpt %d, feat %d)", L, P.n_hops, P.reg_nd, P.reg_kpt, P.feat);
+      fail(CE_ERR_UNSUPPORTED, "no kernel for (layers %d, hops %d, reg_nd %d, kpt %d, feat %d, narrow %d)", L, P.n_hops, P.reg_nd, P.reg_kpt, P.feat, P.narrow);
       ce_plan_destroy(p);
       return CE_ERR_UNSUPPORTED;
     }
@@ -607,7 +627,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   // The wide single-hop none / mean kernel needs 114 VGPRs and little LDS: four workgroups fit a CU, but from a few rounds of
   // work on it runs 2-4 % faster with two (in-process A/B: 2048 x 4 items -4.3 %, 8192 x 4 -2.1 %; 1024 x 1 +2.5 %), so large
   // launches request as much dynamic LDS as leaves room for two.  Placement only: results are unaffected.
-  if (e == hipSuccess && P.n_hops == 1 && L == 1 && P.reg_nd == 2 && P.reg_kpt == CE_KPT && P.feat == 0 && lay.total <= CE_LDS_BIG_BYTES &&
+  if (e == hipSuccess && !P.narrow && P.n_hops == 1 && L == 1 && P.reg_nd == 2 && P.reg_kpt == CE_KPT && P.feat == 0 && lay.total <= CE_LDS_BIG_BYTES &&
       !ce_knob("CE_NO_LDS_BIG")) {
     int nb2 = 1;
     CeLaunchCtx c2 = {};
@@ -635,7 +655,7 @@ int ce_plan_derive_host(const ce_plan_desc* d, ce_plan_host_view* v) {
   memset(v, 0, sizeof(*v));
   v->n_re = P.n_re; v->n_dmrs_total = p->info.n_dmrs_total; v->n_pils = P.n_pils; v->rc_len = P.rc_len;
   v->reg_nd = P.reg_nd; v->lds_bytes = p->info.lds_bytes; v->scratch_bytes = P.scratch_bytes;
-  v->filt_windowed = P.filt_windowed; v->cfo_estimated = P.cfo_estimated;
+  v->filt_windowed = P.filt_windowed; v->cfo_estimated = P.cfo_estimated; v->narrow = P.narrow;
   v->n_pilots = P.n_pilots; v->noise_den = P.noise_den;
   for (int i = 0; i < CE_MAX_RC_TAPS; ++i) v->rc[i] = P.rc[i];
   for (int i = 0; i < CE_MAX_SYMBOLS; ++i) v->sst[i] = P.sst[i];

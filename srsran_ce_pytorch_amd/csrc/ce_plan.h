@@ -159,6 +159,10 @@ struct alignas(16) CeDevPlan {
   // extension: block LMMSE smoothing (CE_SMOOTH_MMSE)
   int32_t mmse_nb, mmse_nbp;          // blocks of CE_MMSE_BLOCK pilots, padded to a multiple of 16 (MFMA N tiles)
   double cnn_rcp[5];                  // 1 / (code/4 + 1e-12), code = m[i-1] + 2 m[i] + m[i+1] (src/ce_dl_cnn.py:498-501)
+  // wave-per-item kernel (ce_narrow_kernel.h) for narrow allocations: narrow = 1 when the plan runs on it
+  int32_t narrow, nrw_nd_max;         // nrw_nd_max: most DM-RS symbols in a hop (sizes the per-wave staging rows)
+  uint32_t nrw_magic_nre;             // floor(2^32 / n_re) + 1: idx / n_re == umulhi(idx, magic) for idx < 2^16
+  int32_t nrw_pad;
   CeDevHop hop[CE_MAX_HOPS];
 };
 
@@ -195,6 +199,42 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
   l.off_rcz = o;                                                 // (the RC taps are read from the LDS plan copy)
   l.off_plan = o;     o += (int)((sizeof(CeDevPlan) + 15) & ~15); // LDS copy of the plan (no scalar loads from global later)
   l.total = (o + 15) & ~15;
+  return l;
+}
+
+// ---- wave-per-item kernel for narrow allocations (ce_narrow_kernel.h) ----
+// A 256-thread workgroup carries CE_THREADS / 64 work items, one per wave; after one workgroup barrier (plan + twiddle copy)
+// the waves never synchronise with each other again.  Shared: LDS copy of the plan, the TA twiddles.  Per wave: the hop's
+// received pilots and DM-RS symbols (staged once per hop: rows of n_re_pad), P, virtual pilots, phasor tables.
+#define CE_NARROW_MAX_RE 192          // pilots per DM-RS symbol and CDM group (<= 3 per lane): 32 PRB at comb 2, 16 PRB with every RE a pilot
+#ifndef CE_NARROW_MIN_RE
+#define CE_NARROW_MIN_RE 1            // (policy knob of A/B builds: plans below this many pilots stay on the workgroup-per-item kernels)
+#endif
+#ifndef CE_NARROW_LDS_LIMIT
+#define CE_NARROW_LDS_LIMIT (40 * 1024)   // dynamic LDS per workgroup up to which a plan takes the kernel (4 workgroups = 16 items per CU)
+#endif
+#ifndef CE_NARROW_MIN_WAVES
+#define CE_NARROW_MIN_WAVES 4         // waves per SIMD the register allocator leaves room for (128 VGPRs)
+#endif
+struct CeNarrowLayout {
+  int32_t off_plan, off_tw, off_wave0, wave_stride;   // bytes
+  int32_t stage_off, p_off, vp_off, rot_off;          // inside a wave's region, bytes
+  int32_t total;
+};
+static inline __host__ __device__ CeNarrowLayout ce_narrow_layout(int n_hops, int n_layers, int nd_max, int n_re_pad) {
+  CeNarrowLayout l;
+  const int n_cdm = (n_layers + 1) / 2;
+  int o = 0;
+  l.off_plan = o;   o += (int)((sizeof(CeDevPlan) + 15) & ~15);
+  l.off_tw = o;     o += (256 + 16) * 8;
+  l.off_wave0 = o;
+  int w = 0;
+  l.stage_off = w;  w += (n_cdm + n_layers) * nd_max * n_re_pad * 8;   // [rx: cdm][symbol][n_re_pad] then [pilots: layer][symbol][n_re_pad]
+  l.p_off = w;      w += n_hops * n_layers * n_re_pad * 8;
+  l.vp_off = w;     w += 128 * 8;                                      // virtual pilots [2 layers][head, tail][16]; later the TA's [4 rows][2][16]
+  l.rot_off = w;    w += (16 + CE_MAX_HOPS * 8) * 8;                   // final[16] | per hop: -phasors[4], +phasors[4]
+  l.wave_stride = (w + 15) & ~15;
+  l.total = l.off_wave0 + (CE_THREADS / 64) * l.wave_stride;
   return l;
 }
 
@@ -243,5 +283,6 @@ int ce_tu_reg_h2_f0(int op, int key, const CeLaunchCtx& c);   // two hops
 int ce_tu_reg_h2_f1(int op, int key, const CeLaunchCtx& c);
 int ce_tu_gen_h1(int op, int key, const CeLaunchCtx& c);      // re-read path (1-4 layers), every feature set; + the wide headline kernel with extensions
 int ce_tu_gen_h2(int op, int key, const CeLaunchCtx& c);
+int ce_tu_narrow(int op, int key, const CeLaunchCtx& c);      // wave-per-item kernel: key = layers * 10 + hops
 // whether the register path (reg_nd > 0) has an instantiation carrying CE_FEAT_EXT for this shape
 static inline bool ce_reg_has_ext(int n_hops, int reg_nd, int reg_kpt) { return n_hops == 1 && reg_nd == 2 && reg_kpt >= 2; }
