@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
         float2 s1[9];
 #pragma unroll
         for (int m = 0; m < 9; ++m) {
-          const int kd = co + 16 * m, ka = CE_FFT_SIZE - 2 * CE_TA_HALF + co + 16 * m;
+          const int kd = co + 16 * m, ka = CE_FFT_SIZE - CE_TA_HALF + co + 16 * m;
           const int md = (r * kd) & (CE_FFT_SIZE - 1), ma = (r * ka) & (CE_FFT_SIZE - 1);   // W4096^(r k)
           const float2 td = cmul(cmul(tw256[md >> 4], tw16[md & 15]), v[idft16_at(m)]);
           const float2 ta = cmul(cmul(tw256[ma >> 4], tw16[ma & 15]), v[idft16_at(7 + m)]);

@@ -48,30 +48,54 @@ np.savez(sys.argv[2], **out)
 ''' % (str(ROOT), str(ROOT / "tests"))
 
 
-def _run(tmp_path, knob):
+def _run(tmp_path, knob, also=()):
     env = dict(os.environ)
     env.pop("CE_HIP_LIB", None)
     if knob:
         if not _lib.KNOBS_LIB_PATH.exists():
             _lib.build(force=True)
-        env[knob] = "1"
+        for k in (knob,) + tuple(also):
+            env[k] = "1"
         env["CE_HIP_LIB"] = str(_lib.KNOBS_LIB_PATH)
-    dst = tmp_path / f"tier_{knob or 'default'}.npz"
+    dst = tmp_path / f"tier_{knob or 'default'}{'_'.join(also)}.npz"
     p = subprocess.run([sys.executable, "-c", CHILD, json.dumps(CASES), str(dst)], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     return np.load(dst)
 
 
 @pytest.fixture(scope="module")
-def default_results(tmp_path_factory):
+def shipped_results(tmp_path_factory):
+    """The shipped library's own choice of kernel for every case (narrow allocations: the wave-per-item kernel)."""
     return _run(tmp_path_factory.mktemp("tiers"), None)
+
+
+@pytest.fixture(scope="module")
+def default_results(tmp_path_factory):
+    """The workgroup-per-item kernels' default path for every case (CE_NO_NARROW): what their knobs are compared with."""
+    return _run(tmp_path_factory.mktemp("tiers_wg"), "CE_NO_NARROW")
+
+
+def test_wave_per_item_kernel_agrees_with_the_workgroup_per_item_kernels(shipped_results, default_results):
+    """ce_narrow_kernel.h against ce_estimate_kernel.h on the narrow cases: same arithmetic per stage, sums in another
+    order (wave sums / the TA's cross-row reduce-scatter) -- agreement to rounding, time alignment identical."""
+    narrow = 0
+    for c in CASES:
+        n = c["name"]
+        ch0, ch1 = default_results[n + "/ch"], shipped_results[n + "/ch"]
+        narrow += int(not np.array_equal(ch0, ch1))
+        assert np.abs(ch0 - ch1).max() <= 2e-6 * np.abs(ch0).max(), n
+        assert np.array_equal(default_results[n + "/ta"], shipped_results[n + "/ta"]), f"{n} time alignment"
+        for k in ("noise", "rsrp", "epre", "cfo"):
+            a, b = default_results[n + "/" + k], shipped_results[n + "/" + k]
+            assert np.allclose(a, b, rtol=2e-6, atol=1e-9 if k != "cfo" else 1e-3), f"{n} {k}: {a} vs {b}"
+    assert narrow >= 3, "the narrow cases of the set should run on the wave-per-item kernel by default"
 
 
 # knob -> results must be bit-identical to the default path's (the knob only changes where data waits or how a transform is pruned?)
 @pytest.mark.parametrize("knob,bitwise", [("CE_NO_PIL_STASH", True), ("CE_TA_LP1", True), ("CE_TA_FULL", False),
                                           ("CE_FORCE_GENERIC", False), ("CE_FORCE_WIDE", False)])
 def test_alternative_kernel_paths_agree(tmp_path, default_results, knob, bitwise):
-    alt = _run(tmp_path, knob)
+    alt = _run(tmp_path, knob, also=("CE_NO_NARROW",))
     for c in CASES:
         n = c["name"]
         ch0, ch1 = default_results[n + "/ch"], alt[n + "/ch"]

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--slots", type=int, default=8192)
     ap.add_argument("--ports", type=int, default=4)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--only", default="")
+    ap.add_argument("--only", default="", help="comma-separated substrings of case names")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     import torch
@@ -42,7 +42,7 @@ def main():
           f"{names[-1]} vs {names[0]} by medians")
     print(f"{'case':42s}" + "".join(f"{n:>18s}" for n in names))
     for cname, case, interp in CASES:
-        if a.only not in cname:
+        if not any(o in cname for o in a.only.split(",")):
             continue
         h1, h2, cfg = S.numpy_hops(case)
         rx, pil = S.torch_inputs(case, a.slots, a.ports, dev, 1)
