@@ -175,6 +175,7 @@ int ce_time_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[
  *   CE_LDS_PAD_BYTES   extra dynamic LDS per workgroup (lowers the workgroups resident per CU)
  *   CE_NO_LDS_BIG      no 80 KB LDS request for large launches of the wide none / mean kernel
  *   CE_NO_NARROW       narrow allocations on the workgroup-per-item kernels instead of the wave-per-item kernel
+ *   CE_FORCE_NARROW    the wave-per-item kernel for every plan it covers, also where the policy prefers the other kernels
  * Knobs are not part of the host-side plan-cache key: set them before the process creates its first plan.
  */
 const char* ce_last_error(void);

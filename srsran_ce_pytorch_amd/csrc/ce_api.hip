@@ -561,14 +561,21 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
       nd_max = std::max(nd_max, (int)P.hop[h].n_dmrs);
       win_ok = win_ok && P.hop[h].ta_win != 0u;
     }
+    int h_max = 0;
+    for (int h = 0; h < d->n_hops; ++h) h_max = std::max(h_max, (int)P.hop[h].n_sc_hop);
     P.nrw_nd_max = nd_max;
+    P.nrw_h_stride = (h_max + 1) & ~1;
     P.nrw_magic_nre = (uint32_t)(0x100000000ull / (unsigned)n_re) + 1u;
-    const CeNarrowLayout nl = ce_narrow_layout(P.n_hops, L, nd_max, P.n_re_pad);
+    const CeNarrowLayout nl = ce_narrow_layout(P.n_hops, L, nd_max, P.n_re_pad, P.nrw_h_stride);
+    // Where it pays (in-process A/B over tools/perf_cases.py, profiles/round3_narrow_kernel_ab.txt): every two-hop and every
+    // multi-layer narrow shape (-13 ... -52 %), and one-hop one-layer allocations of a few PRB (3 PRB: -6 %); from about 6 PRB
+    // on, the one-hop one-layer register tiers of ce_estimate_kernel.h (five workgroups per CU) are 3-8 % faster and keep the plan.
+    const bool pays = d->n_hops == 2 || L >= 2 || n_re <= CE_NARROW_1H1L_MAX_RE || ce_knob("CE_FORCE_NARROW");
     P.narrow = (d->interp == CE_INTERP_LINEAR && d->smoothing != CE_SMOOTH_MMSE && d->n_sym == CE_MAX_SYMBOLS && n_re <= CE_NARROW_MAX_RE &&
-                n_re >= CE_NARROW_MIN_RE && win_ok && nl.total <= CE_NARROW_LDS_LIMIT && !ce_knob("CE_NO_NARROW")) ? 1 : 0;
+                pays && win_ok && nl.total <= CE_NARROW_LDS_LIMIT && !ce_knob("CE_NO_NARROW")) ? 1 : 0;
   }
   CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
-  if (P.narrow) lay.total = ce_narrow_layout(P.n_hops, L, P.nrw_nd_max, P.n_re_pad).total;
+  if (P.narrow) lay.total = ce_narrow_layout(P.n_hops, L, P.nrw_nd_max, P.n_re_pad, P.nrw_h_stride).total;
 #ifdef CE_LDS_PAD_DEFAULT   // A/B builds (tools/ab_inproc.py loads several libraries into one process, which share the environment)
   lay.total += CE_LDS_PAD_DEFAULT & ~15;
 #endif

@@ -68,16 +68,21 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
                                                                            const float2* __restrict__ tw, CeKernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NC = (L + 1) / 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the item, its pointers and the wave's LDS region are wave-uniform
   const int n_re = plan->n_re, n_re_pad = plan->n_re_pad;
-  const CeNarrowLayout lay = ce_narrow_layout(NH, L, plan->nrw_nd_max, n_re_pad);
+  const int hs = plan->nrw_h_stride;
+  const CeNarrowLayout lay = ce_narrow_layout(NH, L, plan->nrw_nd_max, n_re_pad, hs);
+  const int prs = n_re_pad + 2 * CE_NARROW_HALO;   // P row stride: [halo | n_re_pad | halo]
   const CeDevPlan* lp = reinterpret_cast<const CeDevPlan*>(smem + lay.off_plan);
   float2* tw256 = reinterpret_cast<float2*>(smem + lay.off_tw);   // [256] W256^j, then [16] W4096^i
   float2* tw16 = tw256 + 256;
   unsigned char* wbase = smem + lay.off_wave0 + wave * lay.wave_stride;
   float2* S = reinterpret_cast<float2*>(wbase + lay.stage_off);   // staged hop: rx rows [c][s], then DM-RS rows [l][s], n_re_pad each
-  float2* P = reinterpret_cast<float2*>(wbase + lay.p_off);       // [NH][L][n_re_pad]
-  float2* vp = reinterpret_cast<float2*>(wbase + lay.vp_off);     // [2 layers][head, tail][16]
+  float2* P = reinterpret_cast<float2*>(wbase + lay.p_off) + CE_NARROW_HALO;   // [NH][L][prs]: row (h, l) starts at P + (h L + l) prs; indices
+                                                                               // -16..-1 and n_re..n_re+15 hold the virtual pilots / zeros
+  float2* xs = reinterpret_cast<float2*>(wbase + lay.vp_off);     // the TA's [4 rows][x0: 16 | x1: 16]
+  float2* Hb = S;                                                 // after the hops: interpolated response [NH][L][hs]
   float2* rot_final = reinterpret_cast<float2*>(wbase + lay.rot_off);   // [16]
   float2* rot_tab = rot_final + 16;                               // per hop: [4] exp(-j ph) at its DM-RS symbols, [4] exp(+j ph)
 
@@ -101,38 +106,39 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
   const float2* pil = a.pil + slot * a.ps_b;
   const float beta_f = lp->beta_f;
   const bool cfo_comp = lp->cfo_comp != 0;
-  const unsigned magic_nre = lp->nrw_magic_nre;
 
   // ------------------------------------------------------------------ S1: one hop's pilots -> per-wave LDS rows
   // Rows: rx of CDM group c at DM-RS symbol s -> row c * nd + s; DM-RS symbol s of layer l -> row (NC + l) * nd + s.
   // All loads of a batch are requested before the first is stored (one round trip per 8 elements per lane).
   auto stage_hop = [&](int h) __attribute__((always_inline)) {
     const CeDevHop& hp = lp->hop[h];
-    const int nd = hp.n_dmrs, rows_rx = NC * nd, total = (NC + L) * nd * n_re;
-    const float inv_nd = 1.0f / (float)nd;
+    const int nd = hp.n_dmrs, rows_rx = NC * nd, rows = (NC + L) * nd;
+    const int kp = (n_re + 63) >> 6, total = rows * kp;   // (row, 64-pilot chunk) pairs: both wave-uniform, decoded on the scalar unit
     PilotMap pm[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) pm[c] = pilot_map(hp, c);
     const int psym0 = hp.pil_sym0;
 #pragma unroll 1
-    for (int base = 0; base < ((CE_NRW_ABLATE & 8) ? 0 : total); base += 64 * 8) {
+    for (int j0 = 0; j0 < ((CE_NRW_ABLATE & 8) ? 0 : total); j0 += 8) {
       float2 v[8];
       int dst[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * 64 + lane;
-        const bool ok = idx < total;
-        const int ii = ok ? idx : 0;
-        const int row = n_re == 1 ? ii : (int)__umulhi((unsigned)ii, magic_nre), k = ii - row * n_re;   // (one pilot: the 33-bit magic does not exist)
+        dst[u] = -1;
+        const int j = j0 + u;
+        if (j >= total) continue;   // wave-uniform: the rest of the batch is empty
+        const int row = kp == 1 ? j : kp == 2 ? (j >> 1) : (int)(((unsigned)j * 43691u) >> 17), kk = j - row * kp;   // j / kp, kp <= 3, j < 2^15
+        const int k = lane + 64 * kk;
+        const bool ok = k < n_re;
+        const int kc = ok ? k : 0;
         const float2* src;
         if (row < rows_rx) {
-          const int c = (int)(((float)row + 0.5f) * inv_nd), s = row - c * nd;
-          int sc = pilot_sc(pm[0], re_idx, k);
-          if (NC > 1 && c == 1) sc = pilot_sc(pm[NC - 1], re_idx, k);
-          src = rx + (int64_t)sc * a.rs_sc + (int64_t)hp.dmrs_sym[s] * a.rs_sym;
+          const int c = (NC > 1 && row >= nd) ? 1 : 0, sy = row - c * nd;
+          const int sc = pilot_sc(pm[NC > 1 ? c : 0], re_idx, kc);
+          src = rx + (int64_t)hp.dmrs_sym[sy] * a.rs_sym + (int64_t)sc * a.rs_sc;
         } else {
-          const int r2 = row - rows_rx, l = (int)(((float)r2 + 0.5f) * inv_nd), s = r2 - l * nd;
-          src = pil + (int64_t)k * a.ps_re + (int64_t)(psym0 + s) * a.ps_sym + (int64_t)l * a.ps_l;
+          const int r2 = row - rows_rx, l = (r2 >= nd ? 1 : 0) + (r2 >= 2 * nd ? 1 : 0) + (r2 >= 3 * nd ? 1 : 0), sy = r2 - l * nd;
+          src = pil + ((int64_t)(psym0 + sy) * a.ps_sym + (int64_t)l * a.ps_l) + (int64_t)kc * a.ps_re;
         }
         v[u] = *src;
         dst[u] = ok ? row * n_re_pad + k : -1;
@@ -147,10 +153,10 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
   auto dump_stage = [&](int st, int h) __attribute__((always_inline)) {   // ce_estimate_batch_stages only (a.stage_p null otherwise)
     if (a.stage_p) {
       float2* sp = a.stage_p + ((item * 2 + st) * NH + h) * (int64_t)(L * n_re);
-      const float2* Ph = P + h * L * n_re_pad;
+      const float2* Ph = P + h * L * prs;
       for (int i = lane; i < L * n_re; i += 64) {
         const int l = i / n_re;
-        sp[i] = Ph[l * n_re_pad + (i - l * n_re)];
+        sp[i] = Ph[l * prs + (i - l * n_re)];
       }
     }
   };
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
 #pragma unroll 1
   for (int h = 0; h < NH; ++h) {
     const CeDevHop& lh = lp->hop[h];
-    float2* Ph = P + h * L * n_re_pad;
+    float2* Ph = P + h * L * prs;
     float2* rot_neg = rot_tab + h * 8;
     float2* rot_pos = rot_neg + 4;
     const int nd = lh.n_dmrs;
@@ -230,8 +236,8 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
           acc0 = cadd(acc0, cmul(cmul_conj(x, D[((2 * c) * nd + s) * n_re_pad + k]), rn));
           if (2 * c + 1 < L) acc1 = cadd(acc1, cmul(cmul_conj(x, D[((2 * c + 1) * nd + s) * n_re_pad + k]), rn));
         }
-        Ph[(2 * c) * n_re_pad + k] = make_float2(acc0.x / beta_f / nd_f, acc0.y / beta_f / nd_f);
-        if (2 * c + 1 < L) Ph[(2 * c + 1) * n_re_pad + k] = make_float2(acc1.x / beta_f / nd_f, acc1.y / beta_f / nd_f);
+        Ph[(2 * c) * prs + k] = make_float2(acc0.x / beta_f / nd_f, acc0.y / beta_f / nd_f);
+        if (2 * c + 1 < L) Ph[(2 * c + 1) * prs + k] = make_float2(acc1.x / beta_f / nd_f, acc1.y / beta_f / nd_f);
       }
     }
     wave_sync();
@@ -241,10 +247,10 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
       for (int i = lane; i < n_re / 2; i += 64) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-          const float2 u = Ph[l * n_re_pad + 2 * i], v = Ph[l * n_re_pad + 2 * i + 1];
+          const float2 u = Ph[l * prs + 2 * i], v = Ph[l * prs + 2 * i + 1];
           const float2 m = make_float2((u.x + v.x) / 2.f, (u.y + v.y) / 2.f);
-          Ph[l * n_re_pad + 2 * i] = m;
-          Ph[l * n_re_pad + 2 * i + 1] = m;
+          Ph[l * prs + 2 * i] = m;
+          Ph[l * prs + 2 * i + 1] = m;
         }
       }
       wave_sync();
@@ -258,64 +264,74 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
       for (int l = 0; l < L; ++l) {
         double mr = 0.0, mi = 0.0;
         for (int k = lane; k < n_re; k += 64) {
-          const float2 v = Ph[l * n_re_pad + k];
+          const float2 v = Ph[l * prs + k];
           mr += (double)v.x;
           mi += (double)v.y;
         }
         mr = wave_sum(mr);
         mi = wave_sum(mi);
         const float2 m = make_float2((float)(mr / (double)n_re), (float)(mi / (double)n_re));
-        for (int k = lane; k < n_re; k += 64) Ph[l * n_re_pad + k] = m;
+        for (int k = lane; k < n_re; k += 64) Ph[l * prs + k] = m;
       }
       wave_sync();
     } else if (lp->smoothing == CE_SMOOTH_FILTER) {
       const int n_pils = lp->n_pils, rc_len = lp->rc_len, pad = rc_len / 2;
       const double vmx = lp->vp_mx, vin = lp->vp_inv_n, vid = lp->vp_inv_denom;
       const double* rc = lp->rc;
+      // conv([virtual head ; P ; virtual tail], rc, "same") cropped back to P (T:649-664), float64 MACs (T:477-490).  The
+      // virtual pilots are written INTO the row's halo (index -1 - e and n_re + e for distance e + 1 from the band; zeros
+      // beyond them, up to the filter's reach), so the taps run over one contiguous piece of LDS without a branch.
+      for (int i = lane; i < L * 2 * CE_NARROW_HALO; i += 64) {
+        const int l = i / (2 * CE_NARROW_HALO), j = i - l * (2 * CE_NARROW_HALO);
+        Ph[l * prs + (j < CE_NARROW_HALO ? j - CE_NARROW_HALO : n_re + j - CE_NARROW_HALO)] = make_float2(0.f, 0.f);
+      }
+      wave_sync();
 #pragma unroll 1
       for (int l0 = 0; l0 < L; l0 += 2) {
         {  // virtual pilots of layers l0 (lanes 0-31) and l0 + 1 (lanes 32-63): one 16-lane DPP row per band edge
-          const int sub = lane >> 5, ll = l0 + sub < L ? l0 + sub : l0, e = (lane >> 4) & 1;
-          virtual_pilots(Ph + ll * n_re_pad, n_re, n_pils, e != 0, lane & 15, vmx, vin, vid,
-                         [&](int dist, float2 val) { vp[sub * 32 + e * 16 + dist] = val; });
+          const int sub = lane >> 5, e = (lane >> 4) & 1;
+          const bool on = l0 + sub < L;
+          float2* Pl = Ph + (on ? l0 + sub : l0) * prs;
+          virtual_pilots(Pl, n_re, n_pils, e != 0, lane & 15, vmx, vin, vid,
+                         [&](int dist, float2 val) { if (on) Pl[e ? n_re + dist : -1 - dist] = val; });
         }
         wave_sync();
+      }
 #pragma unroll 1
-        for (int sub = 0; sub < 2 && l0 + sub < L; ++sub) {
-          float2* Pl = Ph + (l0 + sub) * n_re_pad;
-          const float2* vpl = vp + sub * 32;
-          // conv([virtual head ; P ; virtual tail], rc, "same") cropped back to P (T:649-664), float64 MACs (T:477-490);
-          // every output of the row is formed before the first is written
-          double yr[3], yi[3];
+      for (int l = 0; l < L; ++l) {
+        float2* Pl = Ph + l * prs;
+        double yr[3], yi[3];   // every output of the row is formed before the first is written
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const int m = lane + 64 * i;
-            double ar = 0.0, ai = 0.0;
-            if (m < n_re) {
-              for (int j = 0; j < rc_len; ++j) {
-                const int idx = m + pad - j;
-                float2 x = make_float2(0.f, 0.f);
-                if (idx < 0) {
-                  if (-1 - idx < n_pils) x = vpl[-1 - idx];
-                } else if (idx >= n_re) {
-                  if (idx - n_re < n_pils) x = vpl[16 + idx - n_re];
-                } else {
-                  x = Pl[idx];
-                }
-                const double w = rc[j];
-                ar += w * (double)x.x;
-                ai += w * (double)x.y;
-              }
+        for (int i = 0; i < 3; ++i) {
+          yr[i] = yi[i] = 0.0;
+          if (64 * i >= n_re) continue;   // wave-uniform
+          const int m = lane + 64 * i < n_re ? lane + 64 * i : n_re - 1;   // (idle lanes repeat the last output: in-range reads, result unused)
+          const float2* x = Pl + m + pad;   // tap j meets x[-j]
+          double ar = 0.0, ai = 0.0;
+          if (rc_len == 15) {   // the usual case (>= 3 PRB of a comb-2 DM-RS): constant trip count, immediate LDS offsets
+#pragma unroll
+            for (int j = 0; j < 15; ++j) {
+              const float2 v = x[-j];
+              const double w = rc[j];
+              ar += w * (double)v.x;
+              ai += w * (double)v.y;
             }
-            yr[i] = ar;
-            yi[i] = ai;
+          } else {
+            for (int j = 0; j < rc_len; ++j) {
+              const float2 v = x[-j];
+              const double w = rc[j];
+              ar += w * (double)v.x;
+              ai += w * (double)v.y;
+            }
           }
-          wave_sync();
+          yr[i] = ar;
+          yi[i] = ai;
+        }
+        wave_sync();
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const int m = lane + 64 * i;
-            if (m < n_re) Pl[m] = make_float2((float)yr[i], (float)yi[i]);
-          }
+        for (int i = 0; i < 3; ++i) {
+          const int m = lane + 64 * i;
+          if (m < n_re) Pl[m] = make_float2((float)yr[i], (float)yi[i]);
         }
         wave_sync();
       }
@@ -328,13 +344,13 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
       for (int k = lane; k < n_re; k += 64) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-          const float2 v = Ph[l * n_re_pad + k];
+          const float2 v = Ph[l * prs + k];
           rsrp_part += v.x * v.x + v.y * v.y;
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          const float2 h0 = Ph[(2 * c) * n_re_pad + k];
-          const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * n_re_pad + k] : make_float2(0.f, 0.f);
+          const float2 h0 = Ph[(2 * c) * prs + k];
+          const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * prs + k] : make_float2(0.f, 0.f);
           for (int s = 0; s < nd; ++s) {
             const float2 x = X[(c * nd + s) * n_re_pad + k];
             const float2 rp = rot_pos[s];
@@ -383,12 +399,30 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
   wave_sync();
 
   // ------------------------------------------------------------------ S10: interpolate + replicate + CFO ramp
-  // A subcarrier's (14 symbols x L layers) is 7L float4; SCS = 64 / 7L subcarriers per wave iteration, each active lane
-  // owns ONE (symbol pair, layer) float4 phase for the whole item (its two phasors and hop candidates are lane
-  // constants) and a wave iteration stores ACTIVE * 16 contiguous bytes.  Linear interpolation straight from P
-  // (left + alpha (right - left), also AT pilots, as the reference does; T:311-338); the hop of an element is the last hop
-  // whose symbol AND subcarrier range cover it (T:872-896).
+  // (1) Linear interpolation of every (hop, layer) over the hop's band -> H rows in LDS (the staging bytes, free now):
+  //     left + alpha (right - left), also AT pilots, as the reference does; flat beyond the first / last pilot (T:311-338).
+  // (2) A subcarrier's (14 symbols x L layers) is 7L float4; SCS = 64 / 7L subcarriers per wave iteration, each active lane
+  //     owns ONE (symbol pair, layer) float4 phase for the whole item (its two phasors and hop candidates are lane
+  //     constants) and a wave iteration stores ACTIVE * 16 contiguous bytes: one H read, two complex multiplies, one store.
+  //     The hop of an element is the last hop whose symbol AND subcarrier range cover it (T:872-896).
   if (!(CE_NRW_ABLATE & 4)) {
+#pragma unroll 1
+    for (int hl = 0; hl < NH * L; ++hl) {
+      const int h = hl / L, l = hl - h * L, c = l >> 1;
+      const CeDevHop& lh = lp->hop[h];
+      const float2* Pl = P + hl * prs;
+      const int dpp = lh.dpp[c], lastp = lh.last_idx[c], nb = lh.n_sc_hop;
+      for (int p = lane; p < nb; p += 64) {
+        const int q = (int)(((unsigned)p * 0xAAABu) >> 19), r = p - 12 * q;   // p / 12 for p < 2^15
+        const float al = lh.alpha[c][r];
+        int ro = q * dpp + lh.r_ord[c][r], lo = ro - 1;
+        if (p >= lastp) lo = ro = n_re - 1;     // at/after the last pilot: hold (T:316,321)
+        lo = lo < 0 ? 0 : lo;                    // at/before the first pilot: hold (T:315,320)
+        const float2 u = Pl[lo], v = Pl[ro];
+        Hb[hl * hs + p] = make_float2(u.x + al * (v.x - u.x), u.y + al * (v.y - u.y));
+      }
+    }
+    wave_sync();
     constexpr int ROW4 = 7 * L, SCS = 64 / ROW4, ACTIVE = SCS * ROW4;
     const int ph = lane % ROW4, sc_off = lane / ROW4;
     const int n_sc = lp->n_sc;
@@ -396,52 +430,47 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
     const CeDevHop& g1 = lp->hop[NH - 1];
     const int b0 = g0.sc0, n0 = g0.n_sc_hop, b1 = g1.sc0, n1 = g1.n_sc_hop;
     float2 rsel[2];
-    unsigned cand[2];
-    int lsel[2], dppe[2], lastp[2];
+    bool c0[2], c1[2];   // element e's symbol lies in hop 0's / hop 1's symbol range (lane constants)
+    int off0[2], off1[2];   // H row of (hop, layer of element e), as an element offset
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int rem = 2 * ph + e, sym = rem / L, l = rem - sym * L, c = l >> 1;
-      cand[e] = (sym >= g0.sym0 && sym < g0.sym1) ? 1u : 0u;
-      if (NH == 2 && sym >= g1.sym0 && sym < g1.sym1) cand[e] |= 2u;
-      rsel[e] = cand[e] ? rot_final[sym < 16 ? sym : 0] : make_float2(0.f, 0.f);   // rot_final == 1 when no CFO ramp applies
-      lsel[e] = l;
-      dppe[e] = g0.dpp[c];
-      lastp[e] = g0.last_idx[c];       // both hops carry the same RE mask and PRB count (T:869; pilots.shape[0] is shared)
+      const int rem = 2 * ph + e, sym = rem / L, l = rem - sym * L;
+      c0[e] = sym >= g0.sym0 && sym < g0.sym1;
+      c1[e] = NH == 2 && sym >= g1.sym0 && sym < g1.sym1;
+      rsel[e] = (c0[e] || c1[e]) ? rot_final[sym < 16 ? sym : 0] : make_float2(0.f, 0.f);   // rot_final == 1 when no CFO ramp applies
+      off0[e] = l * hs;
+      off1[e] = ((NH - 1) * L + l) * hs;
     }
-    const bool same = L == 1 && cand[0] == cand[1];
-    float4* o = reinterpret_cast<float4*>(a.out + item * ((int64_t)n_sc * 14 * L)) + lane;
+    // wave-uniform store base (scalar registers) + a constant per-lane offset: no per-iteration vector address arithmetic
+    float4* obase = reinterpret_cast<float4*>(a.out + item * ((int64_t)n_sc * 14 * L));
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int n_it = (n_sc + SCS - 1) / SCS;   // wave-uniform trip count
-#pragma unroll 2
-    for (int it = 0; it < n_it; ++it, o += ACTIVE) {
+    const bool act = lane < ACTIVE;
+    // one element: the H value of the last hop whose symbol AND subcarrier range cover it, else +0 -- by selects on the LDS
+    // address and an AND on the bits (exact; no exec-masked regions, so the LDS read and the store of consecutive iterations overlap)
+    auto pick = [&](int e, int d0, int d1, bool in0, bool in1) __attribute__((always_inline)) -> float2 {
+      const bool u1 = in1 && c1[e], u0 = !u1 && in0 && c0[e];
+      const int idx = u1 ? off1[e] + d1 : (u0 ? off0[e] + d0 : 0);
+      const float2 v = Hb[idx];
+      const int m = (u1 || u0) ? -1 : 0;
+      return make_float2(__int_as_float(__float_as_int(v.x) & m), __int_as_float(__float_as_int(v.y) & m));
+    };
+    // one layer and both symbols of every lane's pair in the same hops: the two elements of a float4 are the same H value
+    const bool twin = L == 1 && __builtin_amdgcn_ballot_w64(c0[0] != c0[1] || c1[0] != c1[1]) == 0ull;
+#pragma unroll 1
+    for (int it = 0; it < n_it; ++it) {
       const int sc = sc_off + it * SCS;
-      const bool live = lane < ACTIVE && sc < n_sc;
-      const bool in0 = (unsigned)(sc - b0) < (unsigned)n0, in1 = NH == 2 && (unsigned)(sc - b1) < (unsigned)n1;
-      if (__builtin_amdgcn_ballot_w64(live && (in0 || in1)) == 0ull) {   // no lane of the wave inside a hop's band: zeros
+      const bool live = act && sc < n_sc;
+      const int d0 = sc - b0, d1 = sc - b1;
+      const bool in0 = live && (unsigned)d0 < (unsigned)n0, in1 = NH == 2 && live && (unsigned)d1 < (unsigned)n1;
+      float4* o = obase + (size_t)it * ACTIVE + lane;
+      if (__builtin_amdgcn_ballot_w64(in0 || in1) == 0ull) {   // no lane of the wave inside a hop's band: zeros
         if (live) *o = z4;
         continue;
       }
-      float2 y[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (e == 1 && same) {
-          y[1] = y[0];
-        } else {
-          const bool use1 = in1 && (cand[e] & 2u), use0 = !use1 && in0 && (cand[e] & 1u), valid = live && (use1 || use0);
-          const int p = valid ? sc - (use1 ? b1 : b0) : 0;
-          const int q = (int)(((unsigned)p * 0xAAABu) >> 19), r = p - 12 * q;   // p / 12 for p < 2^15
-          const int c = lsel[e] >> 1;
-          const float al = g0.alpha[c][r];
-          int ro = q * dppe[e] + g0.r_ord[c][r], lo = ro - 1;
-          if (p >= lastp[e]) lo = ro = n_re - 1;     // at/after the last pilot: hold (T:316,321)
-          lo = lo < 0 ? 0 : lo;                       // at/before the first pilot: hold (T:315,320)
-          const float2* Pl = P + ((use1 ? L : 0) + lsel[e]) * n_re_pad;
-          const float2 u = Pl[lo], v = Pl[ro];
-          const float2 w = make_float2(u.x + al * (v.x - u.x), u.y + al * (v.y - u.y));
-          y[e] = make_float2(valid ? w.x : 0.f, valid ? w.y : 0.f);
-        }
-      }
-      const float2 ya = cmul(y[0], rsel[0]), yb = cmul(y[1], rsel[1]);
+      const float2 y0 = pick(0, d0, d1, in0, in1);
+      const float2 y1 = twin ? y0 : pick(1, d0, d1, in0, in1);
+      const float2 ya = cmul(y0, rsel[0]), yb = cmul(y1, rsel[1]);
       if (live) *o = make_float4(ya.x, ya.y, yb.x, yb.y);
     }
   }
@@ -478,13 +507,12 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
     // eighteen, and every lane's bins are distinct, so the arg-max key needs no de-duplication.
     const int c = lane & 15, row = lane >> 4;
     const bool adv = (row & 2) != 0, upper = (row & 1) != 0;
-    float2* xs = vp;   // [4 rows][x0: 16 | x1: 16] -- the band's pilots of the round's residues (the virtual-pilot buffer is free now)
     float pw[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) pw[i] = 0.f;
 #pragma unroll 1
     for (int l = 0; l < L; ++l) {
-      const float2* Pl = P + (h * L + l) * n_re_pad;
+      const float2* Pl = P + (h * L + l) * prs;
       float2 acc[5];
 #pragma unroll
       for (int i = 0; i < 5; ++i) acc[i] = make_float2(0.f, 0.f);
@@ -499,27 +527,38 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
         asm volatile("" : "+v"(co));
         {  // lane (row, c) fetches the pilot at subcarrier shift + r + 16 c (and + 256): one position look-up per lane
           const int n0 = shift + r + 16 * c;
-          const int i0 = unit ? pilot_at(n0) : -1, i1 = (unit && two) ? pilot_at(n0 + 256) : -1;
+          const int i0 = unit ? pilot_at(n0) : -1;
           xs[row * 32 + c] = i0 >= 0 ? Pl[i0] : make_float2(0.f, 0.f);
-          xs[row * 32 + 16 + c] = i1 >= 0 ? Pl[i1] : make_float2(0.f, 0.f);
+          if (two) {
+            const int i1 = unit ? pilot_at(n0 + 256) : -1;
+            xs[row * 32 + 16 + c] = i1 >= 0 ? Pl[i1] : make_float2(0.f, 0.f);
+          }
         }
         wave_sync();
         float2 v[16];
-        const float2 wc = tw256[16 * co];   // W16^c
+        if (two) {
+          const float2 wc = tw256[16 * co];   // W16^c
 #pragma unroll
-        for (int aq = 0; aq < 16; ++aq) {
-          const float2 x0 = xs[row * 32 + aq], x1 = xs[row * 32 + 16 + aq];
-          v[aq] = cmul(cadd(x0, cmul(x1, wc)), tw256[(aq * co) & 255]);
+          for (int aq = 0; aq < 16; ++aq) {
+            const float2 x0 = xs[row * 32 + aq], x1 = xs[row * 32 + 16 + aq];
+            v[aq] = cmul(cadd(x0, cmul(x1, wc)), tw256[(aq * co) & 255]);
+          }
+        } else {
+#pragma unroll
+          for (int aq = 0; aq < 16; ++aq) v[aq] = cmul(xs[row * 32 + aq], tw256[(aq * co) & 255]);
         }
         wave_sync();   // (the next round overwrites xs)
         idft16_inplace(v);   // Y_r[c + 16 d] at v[idft16_at(d)]
+        // bin k = c + 16 m (delay side) / 3952 + c + 16 m (advance side): W4096^(r k) = W4096^(r c [+ 3952 r]) W256^(r m) -- one
+        // lane constant per side and one table read per m, shared by the two sides
+        const int md0 = (r * co) & (CE_FFT_SIZE - 1), ma0 = (r * (CE_FFT_SIZE - CE_TA_HALF + co)) & (CE_FFT_SIZE - 1);
+        const float2 wd = cmul(tw256[md0 >> 4], tw16[md0 & 15]), wa = cmul(tw256[ma0 >> 4], tw16[ma0 & 15]);
         float2 s1[9];
 #pragma unroll
         for (int m = 0; m < 9; ++m) {
-          const int kd = co + 16 * m, ka = CE_FFT_SIZE - CE_TA_HALF + co + 16 * m;
-          const int md = (r * kd) & (CE_FFT_SIZE - 1), ma = (r * ka) & (CE_FFT_SIZE - 1);   // W4096^(r k)
-          const float2 td = cmul(cmul(tw256[md >> 4], tw16[md & 15]), v[idft16_at(m)]);
-          const float2 ta = cmul(cmul(tw256[ma >> 4], tw16[ma & 15]), v[idft16_at(7 + m)]);
+          const float2 t = tw256[(r * m) & 255];
+          const float2 td = cmul(cmul(wd, t), v[idft16_at(m)]);
+          const float2 ta = cmul(cmul(wa, t), v[idft16_at(7 + m)]);
           const float2 keep = adv ? ta : td, send = adv ? td : ta;   // rows 2-3 collect the advance side, rows 0-1 the delay side
           s1[m] = make_float2(keep.x + shfl_xor_f(send.x, 32), keep.y + shfl_xor_f(send.y, 32));
         }
