@@ -28,7 +28,8 @@ def golden_names(variant=None):
     for f in sorted(GOLDEN_DIR.glob("*.npz")):
         with np.load(f) as z:
             v = str(z["variant"])
-        if v == "F" or (variant is not None and v != variant):   # "F": fuzz_ta_reference.npz, a table of reference bins, not a slot fixture
+        # "F": fuzz_ta_reference.npz, a table of reference bins, not a slot fixture; "M": complex128-grid fixtures, only on request
+        if v == "F" or (v == "M" and variant != "M") or (variant is not None and v != variant):
             continue
         names.append(f.stem)
     return names
@@ -48,6 +49,8 @@ def load_fixture(name: str) -> SimpleNamespace:
                              ref_ch_est=z["ref_ch_est"], ref_scalars=z["ref_scalars"])
         if "ta_bin" in z:                                   # variant "N": the reference's own arg-max bins and the power around them
             fx.ta_bin, fx.ta_pw = z["ta_bin"], z["ta_pw"]
+        if "pilots_complex128" in z:                        # variant "M": the reference was given a complex128 grid (and these pilots' dtype)
+            fx.pilots_complex128 = bool(z["pilots_complex128"])
     hops = [S._hop_arrays(case, h) for h in case["hops"]]
     fx.hop1 = hops[0]
     fx.hop2 = hops[1] if len(hops) > 1 else S.empty_hop_arrays()

@@ -54,6 +54,18 @@ def test_error_conventions():
         O.srs_channel_estimator(fx.grids[0], fx.pilots, fx.beta, fx.hop1, fx.hop2, fx.config)
 
 
+@pytest.mark.parametrize("name", golden_names("M"))
+def test_complex64_estimate_of_a_complex128_grid_against_the_reference(name):
+    """The reference's outputs for complex128 grids (pilots complex64 as its harness passes them, or complex128) against a
+    complex64 estimate of the same slot -- the oracle's here, the HIP path's in tests/test_hip_parity.py: the pinned
+    distance of the deliberate narrowing."""
+    fx = load_fixture(name)
+    for it in range(fx.grids.shape[0]):
+        out = O.srs_channel_estimator(fx.grids[it], fx.pilots, fx.beta, fx.hop1, fx.hop2, fx.config)
+        got = [out[1], out[2], out[3], out[4], np.nan if out[5] is None else out[5]]
+        check_outputs(out[0], got, fx.ref_ch_est[it], fx.ref_scalars[it], 1e-6, 5e-6, f"{name}[{it}]")
+
+
 def test_oracle_time_alignment_against_the_reference_on_the_fuzz_slice():
     """tests/golden/fuzz_ta_reference.npz holds the REAL reference's arg-max bins and IFFT powers for the GPU suite's fuzz
     cases (tools/make_fuzz_ta_reference.py).  A sample of them on the CPU: the numpy oracle, put through the same protocol the
