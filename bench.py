@@ -240,6 +240,7 @@ def _with_smoothing(cfg, smoothing):
 
 
 def main():
+    t_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -314,6 +315,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    setup_s = time.perf_counter() - t_start      # imports, process group, plan, synthetic inputs resident, first launch (+ the CPU baseline at N = 1)
     elapsed, kernel_ms = time_steps(step, barrier, args.steps, args.warmup,
                                     lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
     elapsed, kernel_ms = max_over_ranks([elapsed, kernel_ms], "cpu" if rehearse else dev)  # measurement only, not data path
@@ -342,7 +344,7 @@ def main():
     line = {
         "metric": "slots/sec (273-PRB PUSCH, 4 Rx)" if n_ports == 4 else f"slots/sec (273-PRB PUSCH, {n_ports} Rx)",
         "value": value, "unit": "slots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "setup_s": setup_s, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearse else ""),
         "config": {"workload": args.workload, "n_prb": 273, "n_sc": plan.n_sc, "n_sym": plan.n_sym, "dmrs_symbols": [2, 11],
                    "layers": 1, "rx_ports": n_ports, "smoothing": wl["smoothing"], "interp": wl.get("interp", "linear"), "slots_per_gpu": n_slots,

@@ -18,7 +18,7 @@ newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 
 def dispatches(d, counter=None):
     rows = list(csv.DictReader(open(newest(f"gpurun_out/{d}/*/*_counter_collection.csv"))))
-    rows = [r for r in rows if "ce_estimate" in r["Kernel_Name"] and (counter is None or r["Counter_Name"] == counter)]
+    rows = [r for r in rows if ("ce_estimate" in r["Kernel_Name"] or "ce_narrow" in r["Kernel_Name"]) and (counter is None or r["Counter_Name"] == counter)]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
 
@@ -35,7 +35,7 @@ def per_geometry(rows, field="Counter_Value"):
 
 res = [dict(o) for o in order]
 tr = list(csv.DictReader(open(newest(f"gpurun_out/{PFX}_geo_trace/*/*_kernel_trace.csv"))))
-tr = [r for r in tr if "ce_estimate" in r["Kernel_Name"]]
+tr = [r for r in tr if "ce_estimate" in r["Kernel_Name"] or "ce_narrow" in r["Kernel_Name"]]
 tr.sort(key=lambda r: int(r["Dispatch_Id"]))
 i = 0
 for r_, o in zip(res, order):

@@ -16,9 +16,15 @@ from srsran_ce_pytorch_amd import estimator as E, synth as S
 from perf_cases import CASES
 
 WANT = ["L1 2dmrs filter (register path)", "L1 2dmrs none", "L1 2 hops x 2dmrs 200 PRB", "L1 2 hops x 3dmrs 200 PRB",
-        "L1 2 hops x 1dmrs 12 PRB in 52", "L1 25 PRB in 52", "L4 2 hops x 2dmrs 136 PRB", "L1 cnn type-2 100 PRB (iterated)"]
+        "L1 2 hops x 1dmrs 12 PRB in 52", "L1 25 PRB in 52", "L4 2 hops x 2dmrs 136 PRB", "L1 cnn type-2 100 PRB (iterated)",
+        # round 3: the multi-layer narrow two-hop row, the reference harness's own shapes (52-PRB grids, 3-PRB allocations; case 4 with
+        # both hops described over the whole slot) and that convention at full band
+        "L2 2 hops x 2dmrs 12 PRB in 52", "harness case0: 3 PRB @40, 4dmrs, 52 grid", "harness case4: 2 hops x 3 PRB, full-slot hops",
+        "harness case8-like: L2 3 PRB 4dmrs", "L1 2 hops x 2dmrs 136 PRB, full-slot hops"]
 LAUNCHES = 4
-WARM = {"L1 2 hops x 1dmrs 12 PRB in 52": 240, "L1 25 PRB in 52": 320, "configs[1]: L1 2dmrs none, 1024 slots x 1 Rx": 400}
+WARM = {"L1 2 hops x 1dmrs 12 PRB in 52": 240, "L1 25 PRB in 52": 320, "configs[1]: L1 2dmrs none, 1024 slots x 1 Rx": 400,
+        "L2 2 hops x 2dmrs 12 PRB in 52": 160, "harness case0: 3 PRB @40, 4dmrs, 52 grid": 320, "harness case4: 2 hops x 3 PRB, full-slot hops": 320,
+        "harness case8-like: L2 3 PRB 4dmrs": 200}
 dev = torch.device("cuda:0")
 order = []
 by_name = {n: (c, i) for n, c, i in CASES}
