@@ -171,7 +171,6 @@ int ce_time_batch(const ce_plan* plan, const void* rx, const int64_t rx_strides[
  *   CE_TA_FULL         full first radix-16 pass of the time-alignment transform instead of the collapsed narrow-band one
  *   CE_TA_LP1          one time-alignment transform at a time (no layer- / hop-parallel form)
  *   CE_NO_PIL_STASH    DM-RS symbols re-read per stage instead of parked in the LDS
- *   CE_NO_TW_LATE      the time-alignment twiddles keep their own LDS bytes (one DM-RS symbol less may fit the stash)
  *   CE_CNN_GENERAL     ce_dl_cnn in-painting always iterated (no closed forms)
  *   CE_LDS_PAD_BYTES   extra dynamic LDS per workgroup (lowers the workgroups resident per CU)
  *   CE_NO_LDS_BIG      no 80 KB LDS request for large launches of the wide none / mean kernel

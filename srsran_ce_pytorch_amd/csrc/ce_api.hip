@@ -540,23 +540,12 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     if (d->interp == CE_INTERP_CNN && P.cnn_alpha > 0.f) smooth_need = std::max(smooth_need, n_re * 8);
     smooth_need = (smooth_need + 15) & ~15;
     const int waves = ce_min_waves(P.n_hops, P.reg_nd, P.reg_kpt, P.feat & 1, L);
-    // as many of the hop's symbols as fit; the rest is re-read in the residual stage.  One more fits when the TA twiddles
-    // give up their own 2 KB: where the TA stage runs after the writer (ce_ta_late) they can sit at the top of the scratch
-    // -- above the TA's residue blocks, over bytes the stash no longer needs by then -- and be fetched right before the stage.
-    const bool late = ce_ta_late(L, P.n_hops, P.reg_nd, P.reg_kpt, P.feat & 1);
-    int ta_need = 0;
-    for (int h = 0; h < d->n_hops; ++h) ta_need = std::max(ta_need, (int)P.hop[h].ta_nres * CE_TA_ROW * 8);
-    bool done = false;
-    for (int nd_st = P.reg_nd; nd_st >= 1 && !done; --nd_st) {
-      for (int twl = 0; twl <= ((late && P.ta_lp == 1 && !ce_knob("CE_NO_TW_LATE")) ? 1 : 0) && !done; ++twl) {
-        int sb = std::max(P.scratch_bytes, smooth_need + nd_st * L * P.n_re_pad * 8);
-        if (twl) sb = std::max(sb, ta_need + (256 + 16) * 8);
-        if (((ce_lds_layout(P.n_hops, L, P.n_re_pad, sb, twl).total + 2047) & ~2047) * waves <= 160 * 1024) {
-          P.pil_stash = (smooth_need / 8) | (nd_st << 24);
-          P.scratch_bytes = sb;
-          P.tw_late = twl;
-          done = true;
-        }
+    for (int nd_st = P.reg_nd; nd_st >= 1; --nd_st) {  // as many of the hop's symbols as fit; the rest is re-read in the residual stage
+      const int sb = std::max(P.scratch_bytes, smooth_need + nd_st * L * P.n_re_pad * 8);
+      if (((ce_lds_layout(P.n_hops, L, P.n_re_pad, sb).total + 2047) & ~2047) * waves <= 160 * 1024) {
+        P.pil_stash = (smooth_need / 8) | (nd_st << 24);
+        P.scratch_bytes = sb;
+        break;
       }
     }
   }
@@ -585,7 +574,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     P.narrow = (d->interp == CE_INTERP_LINEAR && d->smoothing != CE_SMOOTH_MMSE && d->n_sym == CE_MAX_SYMBOLS && n_re <= CE_NARROW_MAX_RE &&
                 pays && win_ok && nl.total <= CE_NARROW_LDS_LIMIT && !ce_knob("CE_NO_NARROW")) ? 1 : 0;
   }
-  CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes, P.tw_late);
+  CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
   if (P.narrow) lay.total = ce_narrow_layout(P.n_hops, L, P.nrw_nd_max, P.n_re_pad, P.nrw_h_stride).total;
 #ifdef CE_LDS_PAD_DEFAULT   // A/B builds (tools/ab_inproc.py loads several libraries into one process, which share the environment)
   lay.total += CE_LDS_PAD_DEFAULT & ~15;

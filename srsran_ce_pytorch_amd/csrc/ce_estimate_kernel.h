@@ -768,8 +768,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
 #endif
 
   const int n_re = plan->n_re, n_re_pad = plan->n_re_pad;
-  const int tw_late = TA_LATE ? plan->tw_late : 0;   // (host: set only for kernels whose TA stage runs after the writer)
-  const CeLdsLayout lay = ce_lds_layout(NH, L, n_re_pad, plan->scratch_bytes, tw_late);
+  const CeLdsLayout lay = ce_lds_layout(NH, L, n_re_pad, plan->scratch_bytes);
   float2* P = reinterpret_cast<float2*>(smem + lay.off_p);              // [NH][L][n_re_pad]
   float2* scratch = reinterpret_cast<float2*>(smem + lay.off_scratch);   // scratch_bytes
   double* red = reinterpret_cast<double*>(smem + lay.off_red);
@@ -791,7 +790,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   static_assert(sizeof(CeDevPlan) % 16 == 0 && PLAN4 <= NT && TW4 <= NT, "one float4 per thread covers the plan and the twiddles");
   float4 plan_v = make_float4(0.f, 0.f, 0.f, 0.f), tw_v = plan_v;
   if (tid < PLAN4) plan_v = reinterpret_cast<const float4*>(plan)[tid];
-  if (tid < TW4 && !tw_late) tw_v = reinterpret_cast<const float4*>(tw + CE_TWC_OFF)[tid];   // W256^j (j < 256) then W4096^i (i < 16), contiguous
+  if (tid < TW4) tw_v = reinterpret_cast<const float4*>(tw + CE_TWC_OFF)[tid];   // W256^j (j < 256) then W4096^i (i < 16), contiguous
   const double* rcz = lp->rcz;                                           // zero-padded RC taps
   const double* sst_l = lp->sst;                                         // [14] symbolStartTime
   const double* sst_dm = &lp->sst_dmrs[0][0];                            // [2][14] ... at the hops' DM-RS symbols
@@ -917,7 +916,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   STAMP_STARTUP(14);  // plan fields arrived in scalar registers, every pilot load issued
   // the copies' LDS stores come after the pilot requests, so waiting for their data does not delay those
   if (tid < PLAN4) reinterpret_cast<float4*>(smem + lay.off_plan)[tid] = plan_v;
-  if (tid < TW4 && !tw_late) reinterpret_cast<float4*>(tw256)[tid] = tw_v;
+  if (tid < TW4) reinterpret_cast<float4*>(tw256)[tid] = tw_v;
   STAMP_STARTUP(15);  // plan and twiddle copies arrived
   const int64_t slot = item / a.n_ports;
   const int port = (int)(item - slot * a.n_ports);
@@ -1914,10 +1913,6 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
     // Nothing the grid needs depends on it, so it runs here, while this workgroup's stores drain: the read ->
     // estimate -> write chain of an item is shorter by this stage, the longest of the estimation.
     __syncthreads();  // the writers are done with the scratch
-    if (tw_late) {    // the twiddles' LDS bytes belonged to the pilot stash until now (plan: tw_late)
-      if (tid < TW4) reinterpret_cast<float4*>(tw256)[tid] = reinterpret_cast<const float4*>(tw + CE_TWC_OFF)[tid];
-      __syncthreads();
-    }
     if (NH == 2 && L == 1 && lp->ta_lp == 2) {
       time_alignment(0, 2);  // both hops' transforms side by side
     } else {

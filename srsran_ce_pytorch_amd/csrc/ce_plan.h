@@ -146,8 +146,7 @@ struct alignas(16) CeDevPlan {
   double rc[CE_MAX_RC_TAPS];          // RC taps, unit sum (T:184-234)
   double rcz[CE_RCZ_LEN];             // the same taps with CE_CONV_C-1 zeros on both sides (windowed FIR)
   double vp_mx, vp_inv_n, vp_inv_denom;  // regression constants of the n_pils-point straight-line fit (T:105-117)
-  int32_t filt_windowed, tw_late;     // filt_windowed 1: n_re <= (CE_THREADS-64)*CE_CONV_C -> sliding-window FIR; tw_late 1: the TA twiddles live at
-                                      // the top of the scratch and are fetched right before the (late) TA stage -- their 2 KB then belong to the pilot stash
+  int32_t filt_windowed, pad1;        // 1: n_re <= (CE_THREADS-64)*CE_CONV_C -> sliding-window FIR
   // ce_dl_cnn.py in-painting (interp == CE_INTERP_CNN): whole-band H per (hop, layer) in the scratch
   int32_t cnn_h_stride;               // complex elements between consecutive (hop, layer) H rows (band-relative: longest hop band, even)
   int32_t ta_lp, pil_stash;           // layers the TA transform handles at a time (1, or 2: ce_estimate_kernel.h time_alignment);
@@ -187,18 +186,16 @@ struct CeLdsLayout {
   int32_t off_p, off_scratch, off_red, off_rot, off_tab, off_misc, off_tw, off_rcz, off_plan, total;
 };
 
-static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_layers, int n_re_pad, int scratch_bytes, int tw_late = 0) {
+static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_layers, int n_re_pad, int scratch_bytes) {
   CeLdsLayout l;
   int o = 0;
   l.off_p = o;        o += n_hops * n_layers * n_re_pad * 8;
   l.off_scratch = o;  o += (scratch_bytes + 15) & ~15;
-  const int scratch_end = o;
   l.off_red = o;      o += (CE_THREADS / 64) * 16 * 8;           // 16 doubles per wave
   l.off_rot = o;      o += (1 + 2 * CE_MAX_HOPS) * 16 * 8;       // final, per-hop -/+ phasors, 16 float2 each
   l.off_tab = o;      o += CE_MAX_HOPS * CE_MAX_CDM * 12 * 8;    // {alpha, r_ord} pairs
   l.off_misc = o;     o += 56 * 8;                               // doubles: cfo_hop[2], ..., TA arg-max keys [2 hops][4 waves][2] at [32]
-  if (tw_late) l.off_tw = scratch_end - (256 + 16) * 8;          // (the host keeps the TA's residue blocks below it)
-  else { l.off_tw = o; o += (256 + 16) * 8; }                    // W256^j, W4096^i for the TA transform
+  l.off_tw = o;       o += (256 + 16) * 8;                       // W256^j, W4096^i for the TA transform
   l.off_rcz = o;                                                 // (the RC taps are read from the LDS plan copy)
   l.off_plan = o;     o += (int)((sizeof(CeDevPlan) + 15) & ~15); // LDS copy of the plan (no scalar loads from global later)
   l.total = (o + 15) & ~15;
