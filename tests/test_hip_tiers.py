@@ -23,6 +23,7 @@ ROOT = Path(__file__).resolve().parents[1]
 CASES = [
     S.case_spec("tier_2hop_200prb", 273, [S.hop_spec([1, 5], 0, 200, 0, 7), S.hop_spec([8, 12], 73, 200, 7, 7)], seed=901),
     S.case_spec("tier_2hop_3dmrs_150prb", 273, [S.hop_spec([0, 3, 6], 10, 150, 0, 7), S.hop_spec([7, 10, 13], 100, 150, 7, 7)], seed=902),
+    S.case_spec("tier_2hop_3dmrs_200prb", 273, [S.hop_spec([0, 3, 6], 0, 200, 0, 7), S.hop_spec([7, 10, 13], 73, 200, 7, 7)], seed=907),
     S.case_spec("tier_25prb", 52, [S.hop_spec([2, 11], 10, 25)], seed=903),
     S.case_spec("tier_2hop_12prb", 52, [S.hop_spec([2], 3, 12, 0, 7), S.hop_spec([9], 30, 12, 7, 7)], seed=904),
     S.case_spec("tier_L2_40prb", 106, [S.hop_spec([2, 11], 20, 40)], n_layers=2, seed=905),
@@ -88,7 +89,7 @@ def test_wave_per_item_kernel_agrees_with_the_workgroup_per_item_kernels(shipped
         for k in ("noise", "rsrp", "epre", "cfo"):
             a, b = default_results[n + "/" + k], shipped_results[n + "/" + k]
             assert np.allclose(a, b, rtol=2e-6, atol=1e-9 if k != "cfo" else 1e-3), f"{n} {k}: {a} vs {b}"
-    assert narrow >= 3, "the narrow cases of the set should run on the wave-per-item kernel by default"
+    assert narrow >= 2, "the narrow two-hop / multi-layer cases of the set should run on the wave-per-item kernel by default"
 
 
 # knob -> results must be bit-identical to the default path's (the knob only changes where data waits or how a transform is pruned?)
