@@ -19,8 +19,9 @@
 //   ta         S8 T:670-698   the pruned 4096-point inverse DFT entirely in registers: lane (residue, c) forms the
 //                             collapsed first radix-16 pass and the second pass for its column, contributes its 18 examined
 //                             bins, two cross-row shuffles add the residues; one arg-max key per hop
-// Plans: interp = linear, smoothing none / mean / filter, 14-symbol grids, <= CE_NARROW_MAX_RE pilots per symbol, every
-// hop's band inside the collapsed TA window (ce_api.hip decides; everything else runs on ce_estimate_kernel.h).
+// Plans: linear interpolation or ce_dl_cnn.py's in-painting in its closed forms (+ the CNNSmoothingAlpha blend), smoothing none /
+// mean / filter, 14-symbol grids, <= CE_NARROW_MAX_RE pilots per symbol, every hop's band inside the collapsed TA window
+// (ce_api.hip decides; everything else -- the iterated in-painting among it -- runs on ce_estimate_kernel.h).
 #pragma once
 #include "ce_estimate_kernel.h"   // shared device helpers (DPP reductions, idft16, virtual_pilots, PilotMap, ...)
 
@@ -335,6 +336,37 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
         }
         wave_sync();
       }
+      if (lp->interp == CE_INTERP_CNN && lp->cnn_alpha > 0.f) {
+        // optional blend with one low-pass pass over the smoothed pilots (src/ce_dl_cnn.py:712-715)
+        const float al = lp->cnn_alpha;
+#pragma unroll 1
+        for (int l = 0; l < L; ++l) {
+          float2* Pl = Ph + l * prs;
+          float2 b[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int k = lane + 64 * i;
+            b[i] = make_float2(0.f, 0.f);
+            if (k < n_re) {
+              const float2 rcv = Pl[k];
+              float2 sm = rcv;
+              if (n_re > 2) {
+                double yr2, yi2;
+                lp3(Pl, k, n_re, &yr2, &yi2);
+                sm = make_float2((float)yr2, (float)yi2);
+              }
+              b[i] = make_float2(rcv.x + al * (sm.x - rcv.x), rcv.y + al * (sm.y - rcv.y));
+            }
+          }
+          wave_sync();
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int k = lane + 64 * i;
+            if (k < n_re) Pl[k] = b[i];
+          }
+          wave_sync();
+        }
+      }
     }
     dump_stage(1, h);
 
@@ -412,14 +444,62 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
       const CeDevHop& lh = lp->hop[h];
       const float2* Pl = P + hl * prs;
       const int dpp = lh.dpp[c], lastp = lh.last_idx[c], nb = lh.n_sc_hop;
-      for (int p = lane; p < nb; p += 64) {
+      auto lin_at = [&](int p) __attribute__((always_inline)) -> float2 {   // T:311-338
         const int q = (int)(((unsigned)p * 0xAAABu) >> 19), r = p - 12 * q;   // p / 12 for p < 2^15
         const float al = lh.alpha[c][r];
         int ro = q * dpp + lh.r_ord[c][r], lo = ro - 1;
         if (p >= lastp) lo = ro = n_re - 1;     // at/after the last pilot: hold (T:316,321)
         lo = lo < 0 ? 0 : lo;                    // at/before the first pilot: hold (T:315,320)
         const float2 u = Pl[lo], v = Pl[ro];
-        Hb[hl * hs + p] = make_float2(u.x + al * (v.x - u.x), u.y + al * (v.y - u.y));
+        return make_float2(u.x + al * (v.x - u.x), u.y + al * (v.y - u.y));
+      };
+      const int cnn_mode = lp->interp == CE_INTERP_CNN ? lp->cnn_comb2 : 0;   // (the iterated in-painting never reaches this kernel)
+      if (cnn_mode == 0) {
+        for (int p = lane; p < nb; p += 64) Hb[hl * hs + p] = lin_at(p);
+      } else if (cnn_mode == 1) {
+        // ce_dl_cnn.py's in-painting + two low-pass passes for a comb-2 DM-RS in closed form (ce_estimate_kernel.h: cnn2_at):
+        // pilots keep their value (C:507-508), an RE between pilots k and k+1 gets (P[k-1] + 15 P[k] + 15 P[k+1] + P[k+2]) / 32,
+        // pilot indices outside the band reflected the way the RE-domain reflect padding (C:433-451) maps them
+        const int off = ((lh.mask12 >> (16 * c)) & 1u) ? 0 : 1, K = n_re - 1;
+        for (int p = lane; p < nb; p += 64) {
+          const int q = p - off;
+          float2 val;
+          if (q >= 0 && !(q & 1)) {
+            val = Pl[q >> 1];
+          } else {
+            const int kl = (q - 1) >> 1;  // pilot on the left (-1: the RE in front of the first pilot)
+            auto refl = [&](int k) { return k < 0 ? -k - off : (k > K ? 2 * K + 1 - off - k : k); };
+            const float2 a0 = Pl[refl(kl - 1)], b0 = Pl[refl(kl)], c0 = Pl[refl(kl + 1)], d0 = Pl[refl(kl + 2)];
+            val = make_float2(((a0.x + d0.x) + 15.f * (b0.x + c0.x)) * (1.f / 32.f), ((a0.y + d0.y) + 15.f * (b0.y + c0.y)) * (1.f / 32.f));
+          }
+          Hb[hl * hs + p] = val;
+        }
+      } else {
+        // any mask whose in-painting reaches its fixed point within the reference's iteration count (ce_estimate_kernel.h:
+        // cnnfp_at): 5-tap binomial (two [1 2 1] / 4 passes, reflect padding C:433-451) over the linear fill, pilots restored
+        const unsigned m12 = (lh.mask12 >> (16 * c)) & 0xFFFu;
+        auto rf = [&](int i) { return i < 0 ? -i : (i >= nb ? 2 * nb - 2 - i : i); };
+        for (int p = lane; p < nb; p += 64) {
+          const int q12 = (int)(((unsigned)p * 0xAAABu) >> 19), r12 = p - 12 * q12;
+          float2 acc = make_float2(0.f, 0.f);
+          if ((m12 >> r12) & 1u) {
+            acc = lin_at(p);   // a pilot RE keeps its value (C:507-508)
+          } else {
+#pragma unroll
+            for (int d = -1; d <= 1; ++d) {
+              const int i = rf(p + d);
+              const float wd = d == 0 ? 0.5f : 0.25f;
+#pragma unroll
+              for (int e = -1; e <= 1; ++e) {
+                const float2 x = lin_at(rf(i + e));
+                const float w = wd * (e == 0 ? 0.5f : 0.25f);
+                acc.x += w * x.x;
+                acc.y += w * x.y;
+              }
+            }
+          }
+          Hb[hl * hs + p] = acc;
+        }
       }
     }
     wave_sync();
