@@ -633,18 +633,19 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
         // lane constant per side and one table read per m, shared by the two sides
         const int md0 = (r * co) & (CE_FFT_SIZE - 1), ma0 = (r * (CE_FFT_SIZE - CE_TA_HALF + co)) & (CE_FFT_SIZE - 1);
         const float2 wd = cmul(tw256[md0 >> 4], tw16[md0 & 15]), wa = cmul(tw256[ma0 >> 4], tw16[ma0 & 15]);
-        float2 s1[9];
-#pragma unroll
-        for (int m = 0; m < 9; ++m) {
+        // rows 2-3 collect the advance side, rows 0-1 the delay side (shuffle over 32 lanes); of a side's nine bins the even row
+        // keeps m = 0..4, the odd row m = 5..8 (shuffle over 16 lanes).  Bins are taken in the order (i, 5 + i) so that a pair
+        // is folded into its accumulator as soon as both halves exist: two first-stage sums live at a time, not nine.
+        auto side_sum = [&](int m) __attribute__((always_inline)) -> float2 {
           const float2 t = tw256[(r * m) & 255];
           const float2 td = cmul(cmul(wd, t), v[idft16_at(m)]);
           const float2 ta = cmul(cmul(wa, t), v[idft16_at(7 + m)]);
-          const float2 keep = adv ? ta : td, send = adv ? td : ta;   // rows 2-3 collect the advance side, rows 0-1 the delay side
-          s1[m] = make_float2(keep.x + shfl_xor_f(send.x, 32), keep.y + shfl_xor_f(send.y, 32));
-        }
+          const float2 keep = adv ? ta : td, send = adv ? td : ta;
+          return make_float2(keep.x + shfl_xor_f(send.x, 32), keep.y + shfl_xor_f(send.y, 32));
+        };
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-          const float2 lo = s1[i], hi = i < 4 ? s1[5 + i] : make_float2(0.f, 0.f);
+          const float2 lo = side_sum(i), hi = i < 4 ? side_sum(5 + i) : make_float2(0.f, 0.f);
           const float2 keep = upper ? hi : lo, send = upper ? lo : hi;
           acc[i].x += keep.x + shfl_xor_f(send.x, 16);
           acc[i].y += keep.y + shfl_xor_f(send.y, 16);

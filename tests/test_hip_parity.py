@@ -273,15 +273,25 @@ def test_unusual_re_masks(mask, smoothing, n_prbs):
         check_outputs(ch[it], got, ref[0], want, TOL_CH, TOL_SC, f"{mask}/{smoothing}/{n_prbs}[{it}]")
 
 
+_PERM_CASES = {
+    # one hop, one layer, 20 PRB: a workgroup-per-item register tier
+    "wg": S.case_spec("perm", 25, [S.hop_spec([2, 11], 3, 20)], seed=77),
+    # two hops x 6 PRB, two layers: the wave-per-item kernel (four items per workgroup, dead waves in the last one)
+    "wave": S.case_spec("perm_nrw", 52, [S.hop_spec([1, 5], 3, 6, 0, 7), S.hop_spec([8, 12], 30, 6, 7, 7)], n_layers=2, seed=78),
+}
+
+
+@pytest.mark.parametrize("kernel", ["wg", "wave"])
 @pytest.mark.parametrize("n_slots,n_ports", [(1, 1), (3, 2), (9, 3), (17, 4), (8, 5), (25, 1), (16, 2), (7, 8)])
-def test_batch_placement_is_a_permutation(n_slots, n_ports):
+def test_batch_placement_is_a_permutation(n_slots, n_ports, kernel):
     """The workgroup -> (slot, port) map deals the ports of a slot 8 workgroups apart (XCD-aware placement,
     `item_of`) and falls back to the identity on the ragged tail: for any batch shape every item must be
     estimated exactly once and from its own slot's pilots -- batch results equal the slot-by-slot results bit
     for bit (same kernel, same arithmetic)."""
     dev = _dev()
-    case = S.case_spec("perm", 25, [S.hop_spec([2, 11], 3, 20)], seed=77)
+    case = _PERM_CASES[kernel]
     h1, h2, cfg = S.numpy_hops(case)
+    assert E.derive_host(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], 14).narrow == (1 if kernel == "wave" else 0)
     rx, pil = S.torch_inputs(case, n_slots, n_ports, dev, seed=5)
     out = E.estimate(rx, pil, case["beta"], h1, h2, cfg)
     for s in range(n_slots):
