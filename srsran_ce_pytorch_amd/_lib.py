@@ -74,7 +74,11 @@ EXPORTS_DENOISE = ["ce_denoiser_create", "ce_denoiser_destroy", "ce_denoise_batc
 # VGPRs (the default AGPR form costs four v_accvgpr_read per 16x16 tile in a kernel bound by vector-instruction issue)
 EXTRA_FLAGS = {"ce_denoise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # wide single-hop FIR kernels (the headline's among them): max-ILP scheduling, 2-3 % faster in process; the narrow tiers lose with it
-               "ce_inst_reg_h1_f1w.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+               "ce_inst_reg_h1_f1w.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+               # the wave-per-item kernel is bound by vector-instruction issue: the SLP vectoriser's packed-f32 forms cost a register
+               # move or two per packed operation there (850 v_mov in one kernel against 465 without) -- in process 10-18 % faster on
+               # the one-layer two-hop shapes without it, 0-4 % on the multi-layer ones (profiles/round3_narrow_kernel_ab.txt)
+               "ce_inst_narrow.hip": ["-fno-slp-vectorize"]}
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: Path | None = None) -> Path:
