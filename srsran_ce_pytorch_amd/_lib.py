@@ -78,7 +78,12 @@ EXTRA_FLAGS = {"ce_denoise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # the wave-per-item kernel is bound by vector-instruction issue: the SLP vectoriser's packed-f32 forms cost a register
                # move or two per packed operation there (850 v_mov in one kernel against 465 without) -- in process 10-18 % faster on
                # the one-layer two-hop shapes without it, 0-4 % on the multi-layer ones (profiles/round3_narrow_kernel_ab.txt)
-               "ce_inst_narrow.hip": ["-fno-slp-vectorize"]}
+               "ce_inst_narrow.hip": ["-fno-slp-vectorize"],
+               # the same for the two-hop and the re-read units (in process, all units without it: two-hop wide tiers -1...-4 %, 2 hops x 40
+               # PRB -7 %, iterated in-painting -5 %, 4 layers x 2 hops -2 %; the one-hop register units are indifferent and keep the default;
+               # profiles/round3_noslp_ab.txt)
+               "ce_inst_reg_h2_f0.hip": ["-fno-slp-vectorize"], "ce_inst_reg_h2_f1.hip": ["-fno-slp-vectorize"],
+               "ce_inst_gen_h1.hip": ["-fno-slp-vectorize"], "ce_inst_gen_h2.hip": ["-fno-slp-vectorize"]}
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: Path | None = None) -> Path:

@@ -32,15 +32,20 @@ def resources(src, flags=()):
 
 def short(name):
     m = re.search(r"ce_estimate_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E", name)
-    return "<L%s,NH%s,ND%s,KPT%s,F%s>" % m.groups() if m else name[:40]
+    if m:
+        return "<L%s,NH%s,ND%s,KPT%s,F%s>" % m.groups()
+    m = re.search(r"ce_narrow_kernelILi(\d)ELi(\d)E", name)
+    return "narrow<L%s,NH%s>" % m.groups() if m else name[:40]
 
 
 if __name__ == "__main__":
     flags = [a for a in sys.argv[1:] if a.startswith("-")]
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
     srcs = [s for s in sorted(CSRC.glob("ce_inst_*.hip")) if not only or any(o in s.name for o in only)]
+    sys.path.insert(0, str(ROOT))
+    from srsran_ce_pytorch_amd._lib import EXTRA_FLAGS   # each unit with its own flags, as the build applies them
     with ThreadPoolExecutor(8) as pool:
-        res = list(pool.map(lambda s: resources(s, flags), srcs))
+        res = list(pool.map(lambda s: resources(s, list(EXTRA_FLAGS.get(s.name, [])) + flags), srcs))
     print(f"{'kernel':26s} {'VGPR':>5s} {'SGPR':>5s} {'spillV':>6s} {'spillS':>6s} {'scratch':>8s} {'occ':>4s}")
     for src, rows in zip(srcs, res):
         print(f"# {src.name}")
