@@ -537,17 +537,23 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
     };
     // one layer and both symbols of every lane's pair in the same hops: the two elements of a float4 are the same H value
     const bool twin = L == 1 && __builtin_amdgcn_ballot_w64(c0[0] != c0[1] || c1[0] != c1[1]) == 0ull;
+    // Iterations whose SCS subcarriers touch a hop's band form one interval per hop (wave-uniform, scalar registers); every
+    // other iteration stores zeros and does nothing else -- in the reference harness's 52-PRB grids with 3-PRB allocations
+    // that is nine iterations of ten.
+    const int lo0 = b0 / SCS, hi0 = (b0 + n0 + SCS - 1) / SCS;
+    const int lo1 = NH == 2 ? b1 / SCS : 0, hi1 = NH == 2 ? (b1 + n1 + SCS - 1) / SCS : 0;
+    const bool last_ok = act && sc_off + (n_it - 1) * SCS < n_sc;   // the last iteration may run past the grid's end
 #pragma unroll 1
     for (int it = 0; it < n_it; ++it) {
-      const int sc = sc_off + it * SCS;
-      const bool live = act && sc < n_sc;
-      const int d0 = sc - b0, d1 = sc - b1;
-      const bool in0 = live && (unsigned)d0 < (unsigned)n0, in1 = NH == 2 && live && (unsigned)d1 < (unsigned)n1;
+      const bool live = it + 1 < n_it ? act : last_ok;
       float4* o = obase + (size_t)it * ACTIVE + lane;
-      if (__builtin_amdgcn_ballot_w64(in0 || in1) == 0ull) {   // no lane of the wave inside a hop's band: zeros
+      if (!((it >= lo0 && it < hi0) || (it >= lo1 && it < hi1))) {
         if (live) *o = z4;
         continue;
       }
+      const int sc = sc_off + it * SCS;
+      const int d0 = sc - b0, d1 = sc - b1;
+      const bool in0 = live && (unsigned)d0 < (unsigned)n0, in1 = NH == 2 && live && (unsigned)d1 < (unsigned)n1;
       const float2 y0 = pick(0, d0, d1, in0, in1);
       const float2 y1 = twin ? y0 : pick(1, d0, d1, in0, in1);
       const float2 ya = cmul(y0, rsel[0]), yb = cmul(y1, rsel[1]);
