@@ -20,7 +20,7 @@
 //                             collapsed first radix-16 pass and the second pass for its column, contributes its 18 examined
 //                             bins, two cross-row shuffles add the residues; one arg-max key per hop
 // Plans: linear interpolation or ce_dl_cnn.py's in-painting in its closed forms (+ the CNNSmoothingAlpha blend), smoothing none /
-// mean / filter, 14-symbol grids, <= CE_NARROW_MAX_RE pilots per symbol, every hop's band inside the collapsed TA window
+// mean / filter, 14- and 12-symbol grids, <= CE_NARROW_MAX_RE pilots per symbol, every hop's band inside the collapsed TA window
 // (ce_api.hip decides; everything else -- the iterated in-painting among it -- runs on ce_estimate_kernel.h).
 #pragma once
 #include "ce_estimate_kernel.h"   // shared device helpers (DPP reductions, idft16, virtual_pilots, PilotMap, ...)
@@ -503,7 +503,12 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
       }
     }
     wave_sync();
-    constexpr int ROW4 = 7 * L, SCS = 64 / ROW4, ACTIVE = SCS * ROW4;
+#ifndef CE_NRW_SCS1
+#define CE_NRW_SCS1 9   // one layer: subcarriers per wave iteration (9 = 63 active lanes, 1008 B; 8 = 56 lanes, 896 B = whole 128-byte lines: measured equal)
+#endif
+    auto store_rows = [&](auto ns2c) __attribute__((always_inline)) {
+    constexpr int NS2 = decltype(ns2c)::value;   // symbol pairs per subcarrier: 7 (14-symbol slot) or 6 (12 symbols: extended CP)
+    constexpr int ROW4 = NS2 * L, SCS = (L == 1 && NS2 == 7) ? CE_NRW_SCS1 : 64 / ROW4, ACTIVE = SCS * ROW4;
     const int ph = lane % ROW4, sc_off = lane / ROW4;
     const int n_sc = lp->n_sc;
     const CeDevHop& g0 = lp->hop[0];
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
       off1[e] = ((NH - 1) * L + l) * hs;
     }
     // wave-uniform store base (scalar registers) + a constant per-lane offset: no per-iteration vector address arithmetic
-    float4* obase = reinterpret_cast<float4*>(a.out + item * ((int64_t)n_sc * 14 * L));
+    float4* obase = reinterpret_cast<float4*>(a.out + item * ((int64_t)n_sc * (2 * NS2) * L));
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int n_it = (n_sc + SCS - 1) / SCS;   // wave-uniform trip count
     const bool act = lane < ACTIVE;
@@ -559,6 +564,9 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
       const float2 ya = cmul(y0, rsel[0]), yb = cmul(y1, rsel[1]);
       if (live) *o = make_float4(ya.x, ya.y, yb.x, yb.y);
     }
+    };   // store_rows
+    if (lp->n_sym == CE_MAX_SYMBOLS) store_rows(std::integral_constant<int, 7>{});
+    else store_rows(std::integral_constant<int, 6>{});   // (the host sends only 14- and 12-symbol grids here)
   }
 
   // ------------------------------------------------------------------ S8: time alignment of each hop, while the stores drain
