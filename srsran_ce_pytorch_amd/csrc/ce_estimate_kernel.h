@@ -582,10 +582,12 @@ __device__ constexpr bool direct_ok() { return SC_STEP % 12 == 0; }  // whole-PR
 // inside the PRB -- hence its interpolation weight and anchor ordinals (T:325-337) -- is constant too:
 // interpolate straight from P in LDS (left + alpha (right - left), also AT pilots, as the reference does), no
 // staging buffer, no barrier.
-template <int L, int NH, int WRU>
+template <int L, int NH, int WRU, int NS2 = 7>
 __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ plan, const float2* P, const float2* tab,
                                                   const float2* rot_final, float4* out4, int n_re, int n_re_pad, int tid) {
-  constexpr int ROW4 = 7 * L, ACTIVE = (NT / 252) * 252, SC_STEP = ACTIVE / ROW4, QS = SC_STEP / 12;
+  // NS2 = symbol pairs per subcarrier: 7 (14-symbol slot), or 6 (12 symbols: 6L float4 per subcarrier, 216 active threads -- the same
+  // 36 / L subcarriers per workgroup iteration)
+  constexpr int ROW4 = NS2 * L, ACTIVE = (NT / (36 * NS2)) * (36 * NS2), SC_STEP = ACTIVE / ROW4, QS = SC_STEP / 12;
   static_assert(SC_STEP % 12 == 0, "direct form needs whole-PRB steps");
   const int ph = tid % ROW4, sc_lane = tid / ROW4, r12 = sc_lane % 12;
   float2 rsel[2];
@@ -684,10 +686,10 @@ __device__ __forceinline__ void write_grid_direct(const CeDevPlan* __restrict__ 
 // host refuses anything else, T:869), so the interpolation weight, the anchor ordinal inside the PRB and the "at / after the
 // last pilot of the PRB" test are hop-independent thread constants; only the P row, the PRB origin and the PRB count are
 // selected per element.  Branch-free body (selects), so unrolled iterations keep their LDS reads in flight together.
-template <int L>
+template <int L, int NS2 = 7>
 __device__ __forceinline__ void write_grid_direct_ovl(const CeDevPlan* __restrict__ plan, const float2* P, const float2* tab,
                                                       const float2* rot_final, float4* out4, int n_re, int n_re_pad, int tid) {
-  constexpr int ROW4 = 7 * L, ACTIVE = (NT / 252) * 252, SC_STEP = ACTIVE / ROW4, QS = SC_STEP / 12;
+  constexpr int ROW4 = NS2 * L, ACTIVE = (NT / (36 * NS2)) * (36 * NS2), SC_STEP = ACTIVE / ROW4, QS = SC_STEP / 12;
   static_assert(SC_STEP % 12 == 0, "direct form needs whole-PRB steps");
   const int ph = tid % ROW4, sc_lane = tid / ROW4, r12 = sc_lane % 12;
   const CeDevHop& h0 = plan->hop[0];
@@ -1736,7 +1738,8 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
   }
 
   if ((CE_ABLATE & 8) || rowwise) {
-  } else if (n_sym == CE_MAX_SYMBOLS) {
+  } else if (n_sym == CE_MAX_SYMBOLS || n_sym == 12) {
+    auto fast_writer = [&](auto ns2c) __attribute__((always_inline)) {
     // Fast writer.  The hop of an element is decided by its symbol alone -- or, for two hops whose fill rectangles share
     // symbols (plan: sym_overlap; the harness's own two-hop convention), by its symbol AND its subcarrier: the last hop
     // whose symbol range (thread constant `cand`) and band cover it (T:872-896).  A subcarrier's (14 symbols x L layers) is 7L float4 and 7L divides 252 for L = 1..4, so
@@ -1744,8 +1747,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
     // its two rotation phasors and hop/layer selection live in registers, and a workgroup iteration
     // stores ACTIVE*16 contiguous bytes.  The interpolated, un-rotated response H[hop][layer][sc] is staged in the LDS
     // scratch, a chunk of subcarriers at a time.
-    constexpr int ROW4 = 7 * L;             // float4 per subcarrier
-    constexpr int ACTIVE = (NT / 252) * 252;
+    constexpr int NS2 = decltype(ns2c)::value;   // symbol pairs per subcarrier: 7, or 6 for 12-symbol grids (extended CP)
+    constexpr int ROW4 = NS2 * L;           // float4 per subcarrier
+    constexpr int ACTIVE = (NT / (36 * NS2)) * (36 * NS2);   // 252 / 216 threads: 36 / L subcarriers per iteration either way
     constexpr int SC_STEP = ACTIVE / ROW4;  // subcarriers per workgroup iteration
     const int ch_log2 = lp->wr_ch_log2, CH = 1 << ch_log2;
     const int ph = tid % ROW4, sc_lane = tid / ROW4;
@@ -1808,9 +1812,9 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         }
       }
     } else if (direct_ok<SC_STEP>() && lp->interp != CE_INTERP_CNN && ovl) {
-      if constexpr (direct_ok<SC_STEP>() && NH == 2) write_grid_direct_ovl<L>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);
+      if constexpr (direct_ok<SC_STEP>() && NH == 2) write_grid_direct_ovl<L, NS2>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);
     } else if (direct_ok<SC_STEP>() && lp->interp != CE_INTERP_CNN) {
-      if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH, (ce_min_waves(NH, ND, KPT, FEAT, L) >= 5 ? 2 : ce_min_waves(NH, ND, KPT, FEAT, L) == 2 ? CE_WR_WIDE : CE_WR_UNROLL)>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);  // (the 96-VGPR tiers have no room for four iterations' operands; 0 = per-element branches: measured 2-4 % faster where only two workgroups share a CU)
+      if constexpr (direct_ok<SC_STEP>()) write_grid_direct<L, NH, (ce_min_waves(NH, ND, KPT, FEAT, L) >= 5 ? 2 : ce_min_waves(NH, ND, KPT, FEAT, L) == 2 ? CE_WR_WIDE : CE_WR_UNROLL), NS2>(lp, P, tab, rot_final, out4, n_re, n_re_pad, tid);  // (the 96-VGPR tiers have no room for four iterations' operands; 0 = per-element branches: measured 2-4 % faster where only two workgroups share a CU)
     } else if (!(CE_LEAN == 1 && direct_ok<SC_STEP>())) {
       const float2* HA = scratch + ((hsel[0] * L + lsel[0]) << ch_log2);
       const float2* HB = scratch + ((hsel[1] * L + lsel[1]) << ch_log2);
@@ -1861,8 +1865,11 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         __syncthreads();
       }
     }
+    };   // fast_writer
+    if (n_sym == CE_MAX_SYMBOLS) fast_writer(std::integral_constant<int, 7>{});
+    else fast_writer(std::integral_constant<int, 6>{});
   } else if (!CE_LEAN) {
-    // generic writer (grids with fewer than 14 symbols, for either interpolator): decode (subcarrier, symbol, layer) per
+    // generic writer (grids of neither 14 nor 12 symbols, for either interpolator): decode (subcarrier, symbol, layer) per
     // element; where the hops' rectangles overlap the later hop wins (T:872-896, src/ce_dl_cnn.py:233-352)
     auto elem = [&](int sc, int rem) -> float2 {
       const int sym = rem / L, l = rem - sym * L;
