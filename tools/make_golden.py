@@ -73,6 +73,12 @@ def golden_cases():
         (CS("hop2_200prb_273", 273, [H([1, 5], 0, 200, 0, 7), H([8, 12], 73, 200, 7, 7)], seed=36), "T", 1),
         (CS("hop2_200prb_3dmrs_273", 273, [H([0, 3, 6], 0, 200, 0, 7), H([7, 10, 13], 73, 200, 7, 7)], seed=37), "T", 1),
         (CS("hop2_12prb_1dmrs_52", 52, [H([2], 3, 12, 0, 7), H([9], 30, 12, 7, 7)], seed=38), "T", 2),
+        # scattered (non-contiguous) PRB masks: the reference extracts pilots through maskPRBs but fills PRBstart .. PRBstart + nPRBs
+        # (T:571-576 vs T:301-304) -- one hop, two hops (the wave-per-item kernel's table look-ups), a wide one, two layers
+        (CS("scatter_6prb_52", 52, [H([2, 11], 10, 6, mask_prbs=[4, 5, 9, 20, 21, 40])], seed=50), "T", 2),
+        (CS("scatter_2hop_4prb_52", 52, [H([1, 5], 3, 4, 0, 7, mask_prbs=[3, 5, 6, 11]), H([8, 12], 30, 4, 7, 7, mask_prbs=[28, 30, 33, 35])], scs=15e3, seed=51), "T", 2),
+        (CS("scatter_100prb_273", 273, [H([2, 11], 60, 100, mask_prbs=list(range(0, 273, 2))[:100])], seed=52), "T", 1),
+        (CS("scatter_layers2_8prb_106", 106, [H([2, 7, 11], 20, 8, mask_prbs=[1, 2, 17, 18, 50, 51, 90, 105])], n_layers=2, smoothing="mean", seed=53), "T", 1),
         (CS("cnn_3prb", 52, [H([2, 11], 7, 3)], seed=20), "C", 2),
         (CS("cnn_type2_3prb", 52, [H([2, 11], 7, 3, re_masks=[S.TYPE2_CDM0])], seed=21), "C", 2),
         (CS("cnn_type2_2hop", 52, [H([2], 3, 3, 0, 7, [S.TYPE2_CDM0]), H([9], 28, 3, 7, 7, [S.TYPE2_CDM0])], seed=23), "C", 1),
