@@ -228,6 +228,22 @@ def secondary_lines(E, S, plan, case, rx, pilots, out, n_slots, n_ports, dev, it
                 "roofline": {"bound": "mfma", "achieved": flops / (best * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": flops / (best * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, "alg_flop_per_launch": flops}})
     torch.cuda.synchronize()
+    # The reference harness's own shapes (52-PRB grids, 3-PRB allocations: scripts/validation/validate_case{0,4,8}.py; case 4 describes
+    # BOTH hops over the whole slot) and the narrow multi-layer two-hop shape: small resident batches of their own, the plans'
+    # own choice of kernel (the wave-per-item kernel, csrc/ce_narrow_kernel.h)
+    H, CS = S.hop_spec, S.case_spec
+    for nm, cs in (("harness52_case4like_2hops_3prb_4rx", CS("hc4", 52, [H([0, 4], 3, 3, 0, 14), H([8, 12], 28, 3, 0, 14)], scs=15e3)),
+                   ("harness52_case0like_3prb_4dmrs_4rx", CS("hc0", 52, [H([0, 4, 8, 12], 40, 3)], scs=15e3)),
+                   ("narrow52_2layers_2hops_12prb_4rx", CS("h2l2n", 52, [H([1, 5], 3, 12, 0, 7), H([8, 12], 30, 12, 7, 7)], n_layers=2))):
+        g1, g2, gcfg = S.numpy_hops(cs)
+        pn = E.make_plan(g1, g2, gcfg, cs["beta"], cs["n_layers"], cs["n_prb_grid"], cs["n_sym"], dev)
+        rxn, piln = S.torch_inputs(cs, n_slots, n_ports, dev, seed=77)
+        outn = E.estimate_with_plan(pn, rxn, piln)
+        e = timed(pn, rxn, piln, outn, n_slots, n_ports, nm, "[slot][port][sym][sc]", cs)
+        e["n_prb_grid"], e["layers"], e["hops"] = cs["n_prb_grid"], cs["n_layers"], len(cs["hops"])
+        res.append(e)
+        del rxn, piln, outn
+    torch.cuda.synchronize()
     return res
 
 
