@@ -566,7 +566,9 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     P.nrw_nd_max = nd_max;
     P.nrw_h_stride = (h_max + 1) & ~1;
     P.nrw_magic_nre = (uint32_t)(0x100000000ull / (unsigned)n_re) + 1u;
-    const CeNarrowLayout nl = ce_narrow_layout(P.n_hops, L, nd_max, P.n_re_pad, P.nrw_h_stride);
+    // halo of a P row = what the RC filter reaches beyond the band: len(rc) / 2 taps, of which n_pils carry virtual pilots (even, so rows stay 16-byte aligned)
+    P.nrw_halo = d->smoothing == CE_SMOOTH_FILTER ? ((std::max(P.rc_len / 2, P.n_pils) + 1) & ~1) : 0;
+    const CeNarrowLayout nl = ce_narrow_layout(P.n_hops, L, nd_max, P.n_re_pad, P.nrw_h_stride, P.nrw_halo);
     // Where it pays (in-process A/B over tools/perf_cases.py, profiles/round3_narrow_kernel_ab.txt): every two-hop and every
     // multi-layer narrow shape (-13 ... -52 %), and one-hop one-layer allocations of a few PRB (3 PRB: -6 %); from about 6 PRB
     // on, the one-hop one-layer register tiers of ce_estimate_kernel.h (five workgroups per CU) are 3-8 % faster and keep the plan.
@@ -576,7 +578,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
                 pays && win_ok && nl.total <= CE_NARROW_LDS_LIMIT && !ce_knob("CE_NO_NARROW")) ? 1 : 0;
   }
   CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
-  if (P.narrow) lay.total = ce_narrow_layout(P.n_hops, L, P.nrw_nd_max, P.n_re_pad, P.nrw_h_stride).total;
+  if (P.narrow) lay.total = ce_narrow_layout(P.n_hops, L, P.nrw_nd_max, P.n_re_pad, P.nrw_h_stride, P.nrw_halo).total;
 #ifdef CE_LDS_PAD_DEFAULT   // A/B builds (tools/ab_inproc.py loads several libraries into one process, which share the environment)
   lay.total += CE_LDS_PAD_DEFAULT & ~15;
 #endif

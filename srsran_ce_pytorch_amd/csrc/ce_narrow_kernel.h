@@ -72,17 +72,17 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the item, its pointers and the wave's LDS region are wave-uniform
   const int n_re = plan->n_re, n_re_pad = plan->n_re_pad;
-  const int hs = plan->nrw_h_stride;
-  const CeNarrowLayout lay = ce_narrow_layout(NH, L, plan->nrw_nd_max, n_re_pad, hs);
-  const int prs = n_re_pad + 2 * CE_NARROW_HALO;   // P row stride: [halo | n_re_pad | halo]
+  const int hs = plan->nrw_h_stride, halo = plan->nrw_halo;
+  const CeNarrowLayout lay = ce_narrow_layout(NH, L, plan->nrw_nd_max, n_re_pad, hs, halo);
+  const int prs = n_re_pad + 2 * halo;   // P row stride: [halo | n_re_pad | halo]; halo = the RC filter's reach (0 without the filter)
   const CeDevPlan* lp = reinterpret_cast<const CeDevPlan*>(smem + lay.off_plan);
   float2* tw256 = reinterpret_cast<float2*>(smem + lay.off_tw);   // [256] W256^j, then [16] W4096^i
   float2* tw16 = tw256 + 256;
   unsigned char* wbase = smem + lay.off_wave0 + wave * lay.wave_stride;
   float2* S = reinterpret_cast<float2*>(wbase + lay.stage_off);   // staged hop: rx rows [c][s], then DM-RS rows [l][s], n_re_pad each
-  float2* P = reinterpret_cast<float2*>(wbase + lay.p_off) + CE_NARROW_HALO;   // [NH][L][prs]: row (h, l) starts at P + (h L + l) prs; indices
-                                                                               // -16..-1 and n_re..n_re+15 hold the virtual pilots / zeros
-  float2* xs = reinterpret_cast<float2*>(wbase + lay.vp_off);     // the TA's [4 rows][x0: 16 | x1: 16]
+  float2* P = reinterpret_cast<float2*>(wbase + lay.p_off) + halo;   // [NH][L][prs]: row (h, l) starts at P + (h L + l) prs; indices
+                                                                     // -halo..-1 and n_re..n_re+halo-1 hold the virtual pilots / zeros
+  float2* xs = reinterpret_cast<float2*>(wbase + lay.vp_off);     // the TA's [4 rows][x0: 16 | x1: 16] (over the staging bytes: free after the writer)
   float2* Hb = S;                                                 // after the hops: interpolated response [NH][L][hs]
   float2* rot_final = reinterpret_cast<float2*>(wbase + lay.rot_off);   // [16]
   float2* rot_tab = rot_final + 16;                               // per hop: [4] exp(-j ph) at its DM-RS symbols, [4] exp(+j ph)
@@ -282,9 +282,9 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
       // conv([virtual head ; P ; virtual tail], rc, "same") cropped back to P (T:649-664), float64 MACs (T:477-490).  The
       // virtual pilots are written INTO the row's halo (index -1 - e and n_re + e for distance e + 1 from the band; zeros
       // beyond them, up to the filter's reach), so the taps run over one contiguous piece of LDS without a branch.
-      for (int i = lane; i < L * 2 * CE_NARROW_HALO; i += 64) {
-        const int l = i / (2 * CE_NARROW_HALO), j = i - l * (2 * CE_NARROW_HALO);
-        Ph[l * prs + (j < CE_NARROW_HALO ? j - CE_NARROW_HALO : n_re + j - CE_NARROW_HALO)] = make_float2(0.f, 0.f);
+      for (int i = lane; i < L * 2 * halo; i += 64) {
+        const int l = i / (2 * halo), j = i - l * (2 * halo);
+        Ph[l * prs + (j < halo ? j - halo : n_re + j - halo)] = make_float2(0.f, 0.f);
       }
       wave_sync();
 #pragma unroll 1
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(NT, CE_NARROW_MIN_WAVES) void ce_narrow_kernel(cons
   // registers and then owns Y_r[c + 16 d], d = 0..15 -- exactly the 18 examined bins k = c + 16 m (d = m) and
   // k = 3952 + c + 16 m (d = 7 + m), m = 0..8, of its column.  Four residues per round (one per 16-lane row).
   double tot_ta = 0.0;
+  wave_sync();   // the pilot buffer `xs` lies over the H rows the writer has just read
 #pragma unroll 1
   for (int h = 0; h < ((CE_NRW_ABLATE & 1) ? 0 : NH); ++h) {
     const CeDevHop& lh = lp->hop[h];

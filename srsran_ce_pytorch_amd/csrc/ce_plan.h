@@ -163,6 +163,7 @@ struct alignas(16) CeDevPlan {
   int32_t narrow, nrw_nd_max;         // nrw_nd_max: most DM-RS symbols in a hop (sizes the per-wave staging rows)
   uint32_t nrw_magic_nre;             // floor(2^32 / n_re) + 1: idx / n_re == umulhi(idx, magic) for idx < 2^16
   int32_t nrw_h_stride;               // complex elements per (hop, layer) row of the interpolated response: widest hop band, even
+  int32_t nrw_halo, nrw_pad[3];       // slots on either side of a P row: the RC filter's reach (virtual pilots + zeros), 0 without the filter
   CeDevHop hop[CE_MAX_HOPS];
 };
 
@@ -207,7 +208,8 @@ static inline __host__ __device__ CeLdsLayout ce_lds_layout(int n_hops, int n_la
 // the waves never synchronise with each other again.  Shared: LDS copy of the plan, the TA twiddles.  Per wave: the hop's
 // received pilots and DM-RS symbols (staged once per hop: rows of n_re_pad), P, virtual pilots, phasor tables.
 #define CE_NARROW_MAX_RE 192          // pilots per DM-RS symbol and CDM group (<= 3 per lane): 32 PRB at comb 2, 16 PRB with every RE a pilot
-#define CE_NARROW_HALO 16             // slots on either side of a P row: virtual pilots (<= 12) and zeros up to the FIR's reach (<= 15)
+#define CE_NARROW_HALO 16             // most slots on either side of a P row: virtual pilots (<= 12) and zeros up to the FIR's reach (<= 15);
+                                      // a plan allocates what its filter reaches (nrw_halo: 7 for the usual 15 taps, 0 without the filter)
 #ifndef CE_NARROW_1H1L_MAX_RE
 #define CE_NARROW_1H1L_MAX_RE 24      // one hop, one layer: pilots per symbol up to which the plan takes the kernel (4 PRB at comb 2)
 #endif
@@ -223,7 +225,7 @@ struct CeNarrowLayout {
   int32_t stage_off, p_off, vp_off, rot_off;          // inside a wave's region, bytes
   int32_t total;
 };
-static inline __host__ __device__ CeNarrowLayout ce_narrow_layout(int n_hops, int n_layers, int nd_max, int n_re_pad, int h_stride) {
+static inline __host__ __device__ CeNarrowLayout ce_narrow_layout(int n_hops, int n_layers, int nd_max, int n_re_pad, int h_stride, int halo) {
   CeNarrowLayout l;
   const int n_cdm = (n_layers + 1) / 2;
   int o = 0;
@@ -234,9 +236,11 @@ static inline __host__ __device__ CeNarrowLayout ce_narrow_layout(int n_hops, in
   // staged hop [rx: cdm][symbol][n_re_pad] then [pilots: layer][symbol][n_re_pad]; after the hops the same bytes hold the
   // interpolated response H [hop][layer][h_stride] the writer streams out
   const int s_bytes = (n_cdm + n_layers) * nd_max * n_re_pad * 8, h_bytes = n_hops * n_layers * h_stride * 8;
-  l.stage_off = w;  w += s_bytes > h_bytes ? s_bytes : h_bytes;
-  l.p_off = w;      w += n_hops * n_layers * (n_re_pad + CE_NARROW_HALO * 2) * 8;   // rows with a halo for the virtual pilots on both sides
-  l.vp_off = w;     w += 128 * 8;                                      // the TA's [4 rows][x0 | x1][16]
+  // ... and after the writer the time alignment's [4 rows][x0 | x1][16] pilot buffer (1 KB)
+  const int sh_bytes = s_bytes > h_bytes ? s_bytes : h_bytes;
+  l.stage_off = w;  w += sh_bytes > 128 * 8 ? sh_bytes : 128 * 8;
+  l.p_off = w;      w += n_hops * n_layers * (n_re_pad + halo * 2) * 8;   // rows with a halo for the virtual pilots on both sides
+  l.vp_off = l.stage_off;                                              // (the TA's pilot buffer: over the staging bytes)
   l.rot_off = w;    w += (16 + CE_MAX_HOPS * 8) * 8;                   // final[16] | per hop: -phasors[4], +phasors[4]
   l.wave_stride = (w + 15) & ~15;
   l.total = l.off_wave0 + (CE_THREADS / 64) * l.wave_stride;
