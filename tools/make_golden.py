@@ -79,6 +79,12 @@ def golden_cases():
         (CS("scatter_2hop_4prb_52", 52, [H([1, 5], 3, 4, 0, 7, mask_prbs=[3, 5, 6, 11]), H([8, 12], 30, 4, 7, 7, mask_prbs=[28, 30, 33, 35])], scs=15e3, seed=51), "T", 2),
         (CS("scatter_100prb_273", 273, [H([2, 11], 60, 100, mask_prbs=list(range(0, 273, 2))[:100])], seed=52), "T", 1),
         (CS("scatter_layers2_8prb_106", 106, [H([2, 7, 11], 20, 8, mask_prbs=[1, 2, 17, 18, 50, 51, 90, 105])], n_layers=2, smoothing="mean", seed=53), "T", 1),
+        # 12-symbol grids (extended CP) with the linear interpolator: no CFO ramp is possible (T:928-929), so one DM-RS symbol or
+        # compensation off -- narrow (wave-per-item kernel), wide one hop, wide two hops over disjoint symbols, two layers
+        (CS("sym12_6prb_1dmrs", 52, [H([3], 10, 6, 0, 12)], n_sym=12, seed=60), "T", 2),
+        (CS("sym12_273prb_nocfo", 273, [H([2, 9], 0, 273, 0, 12)], n_sym=12, cfo_compensate=False, seed=61), "T", 1),
+        (CS("sym12_2hop_100prb_1dmrs", 273, [H([2], 0, 100, 0, 6), H([8], 150, 100, 6, 6)], n_sym=12, seed=62), "T", 1),
+        (CS("sym12_layers2_12prb_nocfo", 52, [H([1, 4], 3, 12, 0, 6), H([7, 10], 30, 12, 6, 6)], n_layers=2, n_sym=12, cfo_compensate=False, smoothing="mean", seed=63), "T", 1),
         (CS("cnn_3prb", 52, [H([2, 11], 7, 3)], seed=20), "C", 2),
         (CS("cnn_type2_3prb", 52, [H([2, 11], 7, 3, re_masks=[S.TYPE2_CDM0])], seed=21), "C", 2),
         (CS("cnn_type2_2hop", 52, [H([2], 3, 3, 0, 7, [S.TYPE2_CDM0]), H([9], 28, 3, 7, 7, [S.TYPE2_CDM0])], seed=23), "C", 1),
