@@ -21,7 +21,7 @@ for name, case, interp in CASES:
     if only not in name:
         continue
     h1, h2, cfg = S.numpy_hops(case)
-    plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], 14, dev, interp)
+    plan = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], case["n_sym"], dev, interp)
     rx, pil = S.torch_inputs(case, slots, ports, dev, 1)
     out = E.estimate_with_plan(plan, rx, pil)
     torch.cuda.synchronize()
