@@ -550,8 +550,8 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     }
   }
   // Narrow allocations run on the wave-per-item kernel (ce_narrow_kernel.h): four items per workgroup, one wave each.
-  // What it covers: linear interpolation and the closed forms of ce_dl_cnn's in-painting (cnn_comb2 != 0), none / mean / filter, 14- and 12-symbol grids, at most CE_NARROW_MAX_RE pilots per symbol,
-  // every hop's band inside the collapsed time-alignment window (ta_win: scattered PRB masks may span more), and a
+  // What it covers: linear interpolation and the closed forms of ce_dl_cnn's in-painting (cnn_comb2 != 0), none / mean / filter, 14- and
+  // 12-symbol grids, at most CE_NARROW_MAX_RE pilots per symbol, every hop's band inside the collapsed time-alignment window (ta_win: scattered PRB masks may span more), and a
   // workgroup's LDS (plan + twiddles + 4 x {staged hop, P, tables}) within CE_NARROW_LDS_LIMIT.  Everything else -- and
   // every plan when the diagnostic build sees CE_NO_NARROW -- takes the workgroup-per-item kernels.
   {
@@ -572,7 +572,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     // Where it pays (in-process A/B over tools/perf_cases.py, profiles/round3_narrow_kernel_ab.txt): every two-hop and every
     // multi-layer narrow shape (-13 ... -52 %), and one-hop one-layer allocations of a few PRB (3 PRB: -6 %); from about 6 PRB
     // on, the one-hop one-layer register tiers of ce_estimate_kernel.h (five workgroups per CU) are 3-8 % faster and keep the plan.
-    // 12-symbol grids (extended CP): the workgroup kernels only have their element-wise writer for them, so every narrow plan pays.
+    // 12-symbol grids (extended CP): every narrow plan (one hop, one layer, 25 PRB: 0.422 vs 0.435 ms through the workgroup kernels' 12-symbol writers).
     const bool pays = d->n_hops == 2 || L >= 2 || n_re <= CE_NARROW_1H1L_MAX_RE || d->n_sym == 12 || ce_knob("CE_FORCE_NARROW");
     P.narrow = ((d->interp == CE_INTERP_LINEAR || P.cnn_comb2 != 0) && d->smoothing != CE_SMOOTH_MMSE && (d->n_sym == CE_MAX_SYMBOLS || d->n_sym == 12) && n_re <= CE_NARROW_MAX_RE &&
                 pays && win_ok && nl.total <= CE_NARROW_LDS_LIMIT && !ce_knob("CE_NO_NARROW")) ? 1 : 0;
