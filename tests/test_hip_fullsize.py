@@ -185,3 +185,36 @@ def test_large_none_launch_with_the_big_lds_request_equals_small_launches():
         assert torch.equal(torch.view_as_real(sub[0]), torch.view_as_real(big[0][sl]))
         for a, b in zip(sub[1:], big[1:]):
             assert torch.equal(a, b[sl])
+
+
+@pytest.mark.parametrize("case", [
+    S.case_spec("nrw_case4like", 52, [S.hop_spec([0, 4], 3, 3, 0, 14), S.hop_spec([8, 12], 28, 3, 0, 14)], scs=15e3, seed=71),
+    S.case_spec("nrw_L2_2hop_12prb", 52, [S.hop_spec([1, 5], 3, 12, 0, 7), S.hop_spec([8, 12], 30, 12, 7, 7)], n_layers=2, seed=72),
+], ids=lambda c: c["name"])
+def test_wave_per_item_kernel_at_full_batch_size(case):
+    """The wave-per-item kernel (csrc/ce_narrow_kernel.h) at the bench's batch size -- 8192 slots x 4 ports = 8192 workgroups of
+    four items: every output written and finite, items independent of the batch (a large launch equals small launches bit for
+    bit, also across the last, partly filled workgroup of an odd-sized batch), and a spot check against the oracle."""
+    dev = torch.device(DEV)
+    h1, h2, cfg = S.numpy_hops(case)
+    L = case["n_layers"]
+    assert E.derive_host(h1, h2, cfg, case["beta"], L, 52, 14).narrow == 1
+    plan = E.make_plan(h1, h2, cfg, case["beta"], L, 52, 14, dev)
+    rx, pil = S.torch_inputs(case, 8192, 4, dev, seed=73)
+    ch = torch.full((8192, 4, 624, 14, L), float("nan"), dtype=torch.complex64, device=dev)
+    sc = torch.full((5, 8192, 4), float("nan"), dtype=torch.float64, device=dev)
+    out = E.estimate_with_plan(plan, rx, pil, (ch, sc[0], sc[1], sc[2], sc[3], sc[4]))
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(torch.view_as_real(out[0])).any())
+    assert all(bool(torch.isfinite(t).all()) for t in out[1:])
+    for a, b in ((0, 3), (4000, 4001), (8189, 8192)):          # 3 slots x 4 ports = 12 items, 1 slot, the batch's last 3 slots
+        part = E.estimate_with_plan(plan, rx[a:b], pil[a:b])
+        for x, y in zip(out, part):
+            assert torch.equal(x[a:b], y), f"slots {a}:{b} differ between the large launch and a small one"
+    odd = E.estimate_with_plan(plan, rx[:5, :3], pil[:5])      # 15 items: the last workgroup carries three live waves
+    for x, y in zip(out, odd):
+        assert torch.equal(x[:5, :3], y)
+    b = S.build_case(case, 1)                                   # same geometry, numpy inputs: the oracle as the checker
+    got = E.estimate(torch.as_tensor(b.grids, device=dev)[None], torch.as_tensor(b.pilots, device=dev), b.beta, b.hop1, b.hop2, b.config)
+    ref = O.srs_channel_estimator(b.grids[0], b.pilots, b.beta, b.hop1, b.hop2, b.config)
+    check_outputs(got[0][0, 0].cpu().numpy(), [float(got[i][0, 0]) for i in range(1, 6)], ref[0], list(ref[1:]), 2e-5, 2e-5, case["name"])
