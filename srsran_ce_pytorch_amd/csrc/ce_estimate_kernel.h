@@ -50,6 +50,12 @@ constexpr double kInvPi = 0.31830988618379067153776752674503;
 #ifndef CE_WR_WIDE
 #define CE_WR_WIDE 0      // the same for the kernels built with the 2-wave bound (0 = per-element branches)
 #endif
+#ifndef CE_GEN_KU
+#define CE_GEN_KU 2       // re-read path: pilot REs per thread whose loads are requested together in the CFO / LS / residual stages (1, 2)
+#endif
+#ifndef CE_GEN_NDC
+#define CE_GEN_NDC 1      // re-read path: LS / residual stages specialised for 1..4 DM-RS symbols (0: run-time symbol loop, A/B builds)
+#endif
 #ifndef CE_WR_UNROLL
 #define CE_WR_UNROLL 4    // direct writer: iterations whose LDS reads are requested together
 #endif
@@ -1236,20 +1242,42 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         PilotMap pmc[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) pmc[c] = pilot_map(hp, c);
-        for (int k = tid; k < n_re; k += NT) {
+        // KU pilot REs per thread and iteration, every load of theirs (2 received REs + 2 x layers DM-RS values per CDM
+        // group) requested before the first is used: the stage is a chain of L2 round trips, one per iteration
+        constexpr int KU = L <= 2 ? CE_GEN_KU : 1;
+        for (int k0 = tid; k0 < n_re; k0 += KU * NT) {
+          float2 x0[KU][NC], x1[KU][NC], q0[KU][NC][2], q1[KU][NC][2];
 #pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const int64_t sc = pilot_sc(pmc[c], re_idx, k);
-            const float2 x0 = rx[sc * a.rs_sc + o0], x1 = rx[sc * a.rs_sc + o1];
+          for (int u = 0; u < KU; ++u) {
+            const int k = (u == 0 || k0 + u * NT < n_re) ? k0 + u * NT : k0;  // past the band: a valid address, the values are dropped
 #pragma unroll
-            for (int l = 2 * c; l < 2 * c + 2 && l < L; ++l) {
-              const float2 q0 = pil[k * a.ps_re + p0 + l * a.ps_l], q1 = pil[k * a.ps_re + p1 + l * a.ps_l];
-              const float2 r0 = cmul_conj(x0, q0), r1 = cmul_conj(x1, q1);
-              const float2 in = cmul_conj(r1, r0);
-              acc[2 * l] += (double)in.x;
-              acc[2 * l + 1] += (double)in.y;
+            for (int c = 0; c < NC; ++c) {
+              const int64_t sc = pilot_sc(pmc[c], re_idx, k);
+              x0[u][c] = rx[sc * a.rs_sc + o0];
+              x1[u][c] = rx[sc * a.rs_sc + o1];
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                if (2 * c + j < L) {
+                  q0[u][c][j] = pil[k * a.ps_re + p0 + (2 * c + j) * a.ps_l];
+                  q1[u][c][j] = pil[k * a.ps_re + p1 + (2 * c + j) * a.ps_l];
+                }
             }
           }
+#pragma unroll
+          for (int u = 0; u < KU; ++u)
+            if (u == 0 || k0 + u * NT < n_re) {
+#pragma unroll
+              for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                  if (2 * c + j < L) {
+                    const int l = 2 * c + j;
+                    const float2 r0 = cmul_conj(x0[u][c], q0[u][c][j]), r1 = cmul_conj(x1[u][c], q1[u][c][j]);
+                    const float2 in = cmul_conj(r1, r0);
+                    acc[2 * l] += (double)in.x;
+                    acc[2 * l + 1] += (double)in.y;
+                  }
+            }
         }
       }
       block_sum<2 * L>(acc, red);
@@ -1309,6 +1337,64 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       PilotMap pmc[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) pmc[c] = pilot_map(lh, c);
+      // The hop's DM-RS symbol count as a compile-time constant (1..4), KU pilot REs per thread and iteration: all their
+      // loads -- n_dmrs received REs and n_dmrs x layers DM-RS values per CDM group -- are requested before the first is
+      // used.  With the symbol loop's trip count a run-time value the stage was one L2 round trip per (RE, CDM group, symbol).
+      // Same operations in the same order either way.
+      auto ls_pass = [&](auto ndc) __attribute__((always_inline)) {
+        constexpr int NDc = decltype(ndc)::value;
+        constexpr int KU = NDc * L <= 4 ? CE_GEN_KU : 1;   // (4 layers x 2 symbols x 2 REs: 166 VGPRs and 1 % slower than one RE per iteration)
+        int64_t osym[NDc], psym[NDc];
+#pragma unroll
+        for (int s = 0; s < NDc; ++s) {
+          osym[s] = lh.dmrs_sym[s] * a.rs_sym;
+          psym[s] = (lh.pil_sym0 + s) * a.ps_sym;
+        }
+        for (int k0 = tid; k0 < n_re; k0 += KU * NT) {
+          float2 x[KU][NC][NDc], q[KU][NC][NDc][2];
+#pragma unroll
+          for (int u = 0; u < KU; ++u) {
+            const int k = (u == 0 || k0 + u * NT < n_re) ? k0 + u * NT : k0;  // past the band: a valid address, the values are dropped
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const int64_t sc = pilot_sc(pmc[c], re_idx, k);
+#pragma unroll
+              for (int s = 0; s < NDc; ++s) {
+                x[u][c][s] = rx[sc * a.rs_sc + osym[s]];
+                q[u][c][s][0] = pil[k * a.ps_re + psym[s] + (2 * c) * a.ps_l];
+                if (2 * c + 1 < L) q[u][c][s][1] = pil[k * a.ps_re + psym[s] + (2 * c + 1) * a.ps_l];
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < KU; ++u) {
+            const int k = k0 + u * NT;
+            if (u == 0 || k < n_re) {
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int s = 0; s < NDc; ++s) {
+                  const float2 xv = x[u][c][s];
+                  epre_part += xv.x * xv.x + xv.y * xv.y;
+                  const float2 rn = rot_neg[s];
+                  acc0 = cadd(acc0, cmul(cmul_conj(xv, q[u][c][s][0]), rn));
+                  if (2 * c + 1 < L) acc1 = cadd(acc1, cmul(cmul_conj(xv, q[u][c][s][1]), rn));
+                }
+                Ph[(2 * c) * n_re_pad + k] = make_float2(acc0.x / beta_f / n_dmrs_f, acc0.y / beta_f / n_dmrs_f);
+                if (2 * c + 1 < L)
+                  Ph[(2 * c + 1) * n_re_pad + k] = make_float2(acc1.x / beta_f / n_dmrs_f, acc1.y / beta_f / n_dmrs_f);
+              }
+            }
+          }
+        }
+      };
+      switch (CE_GEN_NDC ? n_dmrs : 0) {
+        case 1: ls_pass(std::integral_constant<int, 1>{}); break;
+        case 2: ls_pass(std::integral_constant<int, 2>{}); break;
+        case 3: ls_pass(std::integral_constant<int, 3>{}); break;
+        case 4: ls_pass(std::integral_constant<int, 4>{}); break;
+        default:
       for (int k = tid; k < n_re; k += NT) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -1326,6 +1412,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
           if (2 * c + 1 < L)
             Ph[(2 * c + 1) * n_re_pad + k] = make_float2(acc1.x / beta_f / n_dmrs_f, acc1.y / beta_f / n_dmrs_f);
         }
+      }
       }
     }
     __syncthreads();
@@ -1549,7 +1636,67 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         PilotMap pmc[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) pmc[c] = pilot_map(lh, c);
-        for (int k = tid; k < ((CE_ABLATE & 4) ? 0 : n_re); k += NT) {
+        // as in the LS stage: compile-time symbol count, KU pilot REs per iteration, every load requested up front
+        auto resid_pass = [&](auto ndc) __attribute__((always_inline)) {
+          constexpr int NDc = decltype(ndc)::value;
+          constexpr int KU = NDc * L <= 4 ? CE_GEN_KU : 1;   // (4 layers x 2 symbols x 2 REs: 166 VGPRs and 1 % slower than one RE per iteration)
+          int64_t osym[NDc], psym[NDc];
+#pragma unroll
+          for (int s = 0; s < NDc; ++s) {
+            osym[s] = lh.dmrs_sym[s] * a.rs_sym;
+            psym[s] = (lh.pil_sym0 + s) * a.ps_sym;
+          }
+          for (int k0 = tid; k0 < n_re; k0 += KU * NT) {
+            float2 x[KU][NC][NDc], q[KU][NC][NDc][2];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+              const int k = (u == 0 || k0 + u * NT < n_re) ? k0 + u * NT : k0;  // past the band: a valid address, the values are dropped
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                const int64_t sc = pilot_sc(pmc[c], re_idx, k);
+#pragma unroll
+                for (int s = 0; s < NDc; ++s) {
+                  x[u][c][s] = rx[sc * a.rs_sc + osym[s]];
+                  q[u][c][s][0] = pil[k * a.ps_re + psym[s] + (2 * c) * a.ps_l];
+                  if (2 * c + 1 < L) q[u][c][s][1] = pil[k * a.ps_re + psym[s] + (2 * c + 1) * a.ps_l];
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+              const int k = k0 + u * NT;
+              if (u == 0 || k < n_re) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                  const float2 v = Ph[l * n_re_pad + k];
+                  rsrp_part += v.x * v.x + v.y * v.y;
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                  const float2 h0 = Ph[(2 * c) * n_re_pad + k];
+                  const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * n_re_pad + k] : make_float2(0.f, 0.f);
+#pragma unroll
+                  for (int s = 0; s < NDc; ++s) {
+                    const float2 xv = x[u][c][s];
+                    const float2 rp = rot_pos[s];
+                    float2 est = cmul(q[u][c][s][0], cmul(h0, rp));
+                    if (2 * c + 1 < L) est = cadd(est, cmul(q[u][c][s][1], cmul(h1, rp)));
+                    const float dr = xv.x - beta_f * est.x, di = xv.y - beta_f * est.y;
+                    noise_part += dr * dr + di * di;
+                  }
+                }
+              }
+            }
+          }
+        };
+        switch ((CE_ABLATE & 4) ? -1 : CE_GEN_NDC ? n_dmrs : 0) {
+          case -1: break;
+          case 1: resid_pass(std::integral_constant<int, 1>{}); break;
+          case 2: resid_pass(std::integral_constant<int, 2>{}); break;
+          case 3: resid_pass(std::integral_constant<int, 3>{}); break;
+          case 4: resid_pass(std::integral_constant<int, 4>{}); break;
+          default:
+        for (int k = tid; k < n_re; k += NT) {
 #pragma unroll
           for (int l = 0; l < L; ++l) {
             const float2 v = Ph[l * n_re_pad + k];
@@ -1570,6 +1717,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
               noise_part += dr * dr + di * di;
             }
           }
+        }
         }
       }
       double v[3] = {(double)epre_part, (double)noise_part, (double)rsrp_part};
