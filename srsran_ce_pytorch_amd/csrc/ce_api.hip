@@ -452,6 +452,12 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
         }
       P.cnn_comb2 = comb2 ? 1 : converges ? 2 : 0;
     }
+    if (CE_CNNFP_STAGED && P.cnn_comb2 == 2) {
+      // the staged writer evaluates the binomial from a staged linear fill: half the scratch for the H chunk, the other half
+      // (+ two subcarriers either side, per hop and layer) for the fill (ce_estimate_kernel.h: the staged writer)
+      P.wr_ch_log2 = lg - 1;
+      P.scratch_bytes = std::max(P.scratch_bytes, P.n_hops * L * ((2 << P.wr_ch_log2) + 4) * 8);
+    }
     if (d->interp == CE_INTERP_CNN && !P.cnn_comb2) {
       // band-relative H rows for every (hop, layer) + a second x buffer + two mask byte arrays; when all rows together
       // would not fit the LDS (many layers of wide hops) the writer in-paints and stores one row at a time

@@ -1969,6 +1969,54 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
 #pragma unroll 1
       for (int c0 = 0; c0 < lp->n_sc; c0 += CH) {
         const int cn = min(CH, lp->n_sc - c0);
+        if (CE_CNNFP_STAGED && lp->interp == CE_INTERP_CNN && lp->cnn_comb2 == 2) {
+          // ce_dl_cnn's binomial closed form (cnnfp_at) in two steps: the linear fill of the chunk and two subcarriers either
+          // side -> a second LDS row per (hop, layer), then the nine taps from there: one interpolation per RE instead of
+          // nine.  Same terms in the same order (bit-identical); the two REs at either band edge, where the reflect padding
+          // of the two passes matters, keep the direct form.
+          float2* xb = scratch + NH * L * CH;   // [hop x layer][CH + 4] (plan: scratch sized for it)
+#pragma unroll 1
+          for (int hl = 0; hl < NH * L; ++hl) {
+            const int h = hl / L, l = hl - h * L;
+            const int n = lp->hop[h].n_sc_hop, base = c0 - lp->hop[h].sc0;
+            for (int s = tid - 2; s < cn + 2; s += NT) {
+              const int p = base + s;
+              xb[hl * (CH + 4) + s + 2] = (p >= 0 && p < n) ? interp_at(h, l, p) : make_float2(0.f, 0.f);
+            }
+          }
+          __syncthreads();
+          for (int i = tid; i < NH * L * CH; i += NT) {
+            const int s = i & (CH - 1), hl = i >> ch_log2;
+            if (s < cn) {
+              const int h = hl / L, l = hl - h * L;
+              const CeDevHop& lh = lp->hop[h];
+              const int n = lh.n_sc_hop, p = c0 + s - lh.sc0;
+              float2 v = make_float2(0.f, 0.f);
+              if (p >= 0 && p < n) {
+                const float2* x = xb + hl * (CH + 4) + s + 2;
+                const int q12 = p / 12, r12 = p - 12 * q12;
+                if ((lh.mask12 >> (16 * (l >> 1) + r12)) & 1u) {
+                  v = x[0];                                   // a pilot RE keeps its value (C:507-508)
+                } else if (p < 2 || p > n - 3) {
+                  v = cnnfp_at(h, l, p);
+                } else {
+#pragma unroll
+                  for (int d = -1; d <= 1; ++d) {
+                    const float wd = d == 0 ? 0.5f : 0.25f;
+#pragma unroll
+                    for (int e = -1; e <= 1; ++e) {
+                      const float2 xv = x[d + e];
+                      const float w = wd * (e == 0 ? 0.5f : 0.25f);
+                      v.x += w * xv.x;
+                      v.y += w * xv.y;
+                    }
+                  }
+                }
+              }
+              scratch[i] = v;
+            }
+          }
+        } else {
         for (int i = tid; i < NH * L * CH; i += NT) {
           const int s = i & (CH - 1), hl = i >> ch_log2;
           if (s < cn) {
@@ -1979,6 +2027,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
               v = lp->interp != CE_INTERP_CNN ? interp_at(h, l, p) : lp->cnn_comb2 == 1 ? cnn2_at(h, l, p) : cnnfp_at(h, l, p);
             scratch[i] = v;
           }
+        }
         }
         __syncthreads();
         if (ovl) {

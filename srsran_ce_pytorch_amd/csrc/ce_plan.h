@@ -60,6 +60,10 @@
                             // (no shape reaches it: with the DM-RS symbols fetched once per hop and parked in the LDS, three
                             // workgroups per CU beat two with everything in registers -- 3 symbols x 200 PRB: 4.09 -> 3.37 ms)
 #endif
+#ifndef CE_CNNFP_STAGED
+#define CE_CNNFP_STAGED 1   // ce_dl_cnn's binomial closed form (cnn_comb2 == 2) in the staged writer: the linear fill is staged first, then the
+                            // nine taps from LDS (0: nine interpolations per RE; A/B builds).  Kernel and host (scratch sizing) must agree.
+#endif
 // Feature set compiled into an instantiation (template parameter FEAT): a register-path kernel only carries the
 // smoothing code its plans run, so e.g. the headline kernel's register allocation is not shaped by the MFMA block
 // of the mmse extension or the iterated in-painting it never executes.

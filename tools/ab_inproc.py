@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--ports", type=int, default=4)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="", help="comma-separated substrings of case names")
+    ap.add_argument("--check-bits", action="store_true", help="also run every library once into its own outputs and compare them bit for bit with the first library's")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     import torch
@@ -51,12 +52,32 @@ def main():
             plans[n] = E.make_plan(h1, h2, cfg, case["beta"], case["n_layers"], case["n_prb_grid"], case["n_sym"], dev, interp)
             outs[n] = E.estimate_with_plan(plans[n], rx, pil) if not outs else None
         out = next(o for o in outs.values() if o is not None)
+        same = ""
+        if a.check_bits:
+            ref = [o.clone() for o in pk[names[0]].estimate_with_plan(plans[names[0]], rx, pil)]
+            for n in names[1:]:
+                got = pk[n].estimate_with_plan(plans[n], rx, pil)
+                bad = []
+                for nm, g, r in zip(("ch_est", "noise", "rsrp", "epre", "ta", "cfo"), got, ref):
+                    gi, ri = (torch.view_as_real(g), torch.view_as_real(r)) if g.is_complex() else (g.view(torch.int64), r.view(torch.int64))
+                    if not torch.equal(gi, ri):
+                        ne = (gi != ri)
+                        d = (g - r).abs().nan_to_num().max().item() / max(r.abs().nan_to_num().max().item(), 1e-30)
+                        where = ""
+                        if g.is_complex():   # which subcarriers of the first differing item
+                            idx = ne.nonzero()[:1, :2].flatten().tolist()
+                            scs = ne[idx[0], idx[1]].any(-1).any(-1).any(-1).nonzero().flatten()
+                            where = f", item {idx}: {scs.numel()} subcarriers, first {scs[:6].tolist()}, last {scs[-3:].tolist()}"
+                        bad.append(f"{nm} ({int(ne.sum())} words, rel-max {d:.1e}{where})")
+                same += f"  {n}: " + ("bit-identical" if not bad else "DIFFERENT BITS in " + "; ".join(bad))
+                del got
+            del ref
         t = {n: [] for n in names}
         for r in range(a.rounds):
             for n in (names if r % 2 == 0 else names[::-1]):
                 t[n].append(pk[n].time_with_plan(plans[n], rx, pil, out, 1, 5))
         med = {n: st.median(t[n]) for n in names}
-        print(f"{cname:42s}" + "".join(f"{min(t[n]):9.3f} ({med[n]:6.3f})" for n in names) + f"   {100 * (med[names[-1]] / med[names[0]] - 1):+.2f} %", flush=True)
+        print(f"{cname:42s}" + "".join(f"{min(t[n]):9.3f} ({med[n]:6.3f})" for n in names) + f"   {100 * (med[names[-1]] / med[names[0]] - 1):+.2f} %" + same, flush=True)
         del rx, pil, out
     shutil.rmtree(tmp, ignore_errors=True)
 
