@@ -65,8 +65,9 @@ def main():
                         d = (g - r).abs().nan_to_num().max().item() / max(r.abs().nan_to_num().max().item(), 1e-30)
                         where = ""
                         if g.is_complex():   # which subcarriers of the first differing item
-                            idx = ne.nonzero()[:1, :2].flatten().tolist()
-                            scs = ne[idx[0], idx[1]].any(-1).any(-1).any(-1).nonzero().flatten()
+                            items = ne.flatten(2).any(-1)                       # [B][R]
+                            idx = items.nonzero()[0].tolist()
+                            scs = ne[idx[0], idx[1]].flatten(1).any(-1).nonzero().flatten()
                             where = f", item {idx}: {scs.numel()} subcarriers, first {scs[:6].tolist()}, last {scs[-3:].tolist()}"
                         bad.append(f"{nm} ({int(ne.sum())} words, rel-max {d:.1e}{where})")
                 same += f"  {n}: " + ("bit-identical" if not bad else "DIFFERENT BITS in " + "; ".join(bad))
