@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Rewrites the two measured tables of DESIGN.md section 3 ("Measured (round 3 ...)") from the committed profile files, so the
-document cannot drift from them:  profiles/round3_summary.json + round3_bench_line.json + round3_geometry_counters.json (lease B,
-the final head) and profiles/round3_*_cc40bd7.lease.* (lease A).  Prose around the tables is left alone.
+document cannot drift from them:  profiles/round3_summary.json + round3_bench_line.json + round3_geometry_counters.json (the lease of
+the final head) and profiles/round3_*_622852f.lease.* (the previous lease; profiles/round3_*_cc40bd7.lease.* is the one before).  Prose around the tables is left alone.
 
     python tools/regen_design_tables.py        (tables sit between the <!-- lease-table --> / <!-- geometry-table --> markers)"""
 import json, re
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 P = ROOT / "profiles"
-sB, sA = json.loads((P / "round3_summary.json").read_text()), json.loads((P / "round3_summary_cc40bd7.lease.json").read_text())
+sB, sA = json.loads((P / "round3_summary.json").read_text()), json.loads((P / "round3_summary_622852f.lease.json").read_text())
 bB = json.loads((P / "round3_bench_line.json").read_text())
 geo = json.loads((P / "round3_geometry_counters.json").read_text())["geometries"]
 ALG = 13096452096
@@ -31,7 +31,7 @@ B, A = col(sB), col(sA)
 pct = lambda f: f"{100 * f:.1f} %"
 f3 = lambda x: "—" if x != x else f"{x:.3f}"
 f4 = lambda x: "—" if x != x else f"{x:.4f}"
-lease = f"""| item | lease B (final head `{B['head']}`, `rwmix` {B['rw']:.3f} ms) | lease A (head `{A['head']}`, `rwmix` {A['rw']:.3f} ms) |
+lease = f"""| item | final lease (head `{B['head']}`, `rwmix` {B['rw']:.3f} ms) | previous lease (head `{A['head']}`, `rwmix` {A['rw']:.3f} ms) |
 |---|---|---|
 | `bench.py` N=1, `pusch273_4rx_filter` (headline; kernel unchanged since round 2) | {B['bench_ms']:.3f} ms / step = {8192 / B['bench_ms'] / 1e3:.2f} M slots/s = **{pct(B['bench_frac'])}** of 8 TB/s | **{A['bench_ms']:.3f} ms = {8192 / A['bench_ms'] / 1e3:.2f} M slots/s = {pct(A['bench_frac'])}** (driver record of round 2: 2.586 ms = 63.4 %) |
 | rocprofv3 `--kernel-trace --stats`, `ce_estimate_kernel<1,1,2,7,1>`, 24 calls | avg {B['trace_ms']:.3f} ms = {pct(B['trace_frac'])} | avg {A['trace_ms']:.3f} ms = {pct(A['trace_frac'])} |
@@ -41,7 +41,7 @@ lease = f"""| item | lease B (final head `{B['head']}`, `rwmix` {B['rw']:.3f} ms
 | access-pattern bound, same lease (`tools/micro/rwmix.hip`) | {B['rw']:.3f} ms — the kernel ({B['trace_ms']:.3f} traced / {B['bench_ms']:.3f} plain run) is {100 * (B['trace_ms'] / B['rw'] - 1):+.1f} % from it | {A['rw']:.3f} ms — the kernel ({A['trace_ms']:.3f} / {A['bench_ms']:.3f}) is {100 * (A['trace_ms'] / A['rw'] - 1):+.1f} % from it |
 | `secondary`: `configs[1]` `pusch273_1rx_none` (1024 × 1 Rx; one round of workgroups: the spread between processes of round 2, unchanged) | {f4(B['c1'][2])} ms = {pct(B['c1'][3])} | {f4(A['c1'][2])} ms = {pct(A['c1'][3])} |
 | `secondary`: `pusch273_4rx_cnn` / reference `[sc][sym]` layout / `mmse` (unpinned) / Conv2d denoiser (unpinned) | {f3(B['cnn'][2])} ms = {pct(B['cnn'][3])} / {f3(B['ref'][2])} ms = {pct(B['ref'][3])} / {f3(B['mmse'][2])} ms = {pct(B['mmse'][3])} / {B['dn'][2]:.2f} ms = {B['dn'][3]:.3f} of 2.5 PFLOP/s | {f3(A['cnn'][2])} = {pct(A['cnn'][3])} / {f3(A['ref'][2])} = {pct(A['ref'][3])} / {f3(A['mmse'][2])} = {pct(A['mmse'][3])} / {A['dn'][2]:.2f} = {A['dn'][3]:.3f} |
-| `secondary` (new in round 3): case-4-like / case-0-like / 2 layers × 2 hops × 12 PRB, 52-PRB grids, 8192 × 4 | {f3(B['c4'][2])} ms = {pct(B['c4'][3])} / {f3(B['c0'][2])} ms = {pct(B['c0'][3])} / {f3(B['l2'][2])} ms = {pct(B['l2'][3])} | — |
+| `secondary` (new in round 3): case-4-like / case-0-like / 2 layers × 2 hops × 12 PRB, 52-PRB grids, 8192 × 4 | {f3(B['c4'][2])} ms = {pct(B['c4'][3])} / {f3(B['c0'][2])} ms = {pct(B['c0'][3])} / {f3(B['l2'][2])} ms = {pct(B['l2'][3])} | {f3(A['c4'][2])} = {pct(A['c4'][3])} / {f3(A['c0'][2])} = {pct(A['c0'][3])} / {f3(A['l2'][2])} = {pct(A['l2'][3])} |
 | `cpu_baseline` (16 worker processes) | loop-style `ce_rule_baseline` port {B['cpu']['value']:.0f} slots/s, tensorized port {B['cpu']['tensorized_value']:.0f} slots/s | {A['cpu']['value']:.0f} / {A['cpu']['tensorized_value']:.0f} |"""
 rows = [f"| {g['name']} | {g['kernel_us_median'] / 1e3:.3f} | {g['alg_GBps']:.0f} ({100 * g['alg_frac_of_8TBps']:.1f} %) | {g['traffic_over_algorithmic']:.2f} | "
         f"{g.get('wave_parked_frac', float('nan')):.2f} / {g.get('wave_issue_stall_frac', float('nan')):.2f} / {g.get('wave_issuing_frac', float('nan')):.2f} | "
