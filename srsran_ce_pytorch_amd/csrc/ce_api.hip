@@ -557,7 +557,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
   }
   // Narrow allocations run on the wave-per-item kernel (ce_narrow_kernel.h): four items per workgroup, one wave each.
   // What it covers: linear interpolation and the closed forms of ce_dl_cnn's in-painting (cnn_comb2 != 0), none / mean / filter, 14- and
-  // 12-symbol grids, at most CE_NARROW_MAX_RE pilots per symbol, every hop's band inside the collapsed time-alignment window (ta_win: scattered PRB masks may span more), and a
+  // 12-symbol grids, at most CE_NARROW_MAX_RE pilots per symbol, at most four DM-RS symbols per hop, every hop's band inside the collapsed time-alignment window (ta_win: scattered PRB masks may span more), and a
   // workgroup's LDS (plan + twiddles + 4 x {staged hop, P, tables}) within CE_NARROW_LDS_LIMIT.  Everything else -- and
   // every plan when the diagnostic build sees CE_NO_NARROW -- takes the workgroup-per-item kernels.
   {
@@ -581,7 +581,7 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
     // 12-symbol grids (extended CP): every narrow plan (one hop, one layer, 25 PRB: 0.422 vs 0.435 ms through the workgroup kernels' 12-symbol writers).
     const bool pays = d->n_hops == 2 || L >= 2 || n_re <= CE_NARROW_1H1L_MAX_RE || d->n_sym == 12 || ce_knob("CE_FORCE_NARROW");
     P.narrow = ((d->interp == CE_INTERP_LINEAR || P.cnn_comb2 != 0) && d->smoothing != CE_SMOOTH_MMSE && (d->n_sym == CE_MAX_SYMBOLS || d->n_sym == 12) && n_re <= CE_NARROW_MAX_RE &&
-                pays && win_ok && nl.total <= CE_NARROW_LDS_LIMIT && !ce_knob("CE_NO_NARROW")) ? 1 : 0;
+                nd_max <= 4 && pays && win_ok && nl.total <= CE_NARROW_LDS_LIMIT && !ce_knob("CE_NO_NARROW")) ? 1 : 0;   // (its per-hop phasor tables hold four DM-RS symbols)
   }
   CeLdsLayout lay = ce_lds_layout(P.n_hops, L, P.n_re_pad, P.scratch_bytes);
   if (P.narrow) lay.total = ce_narrow_layout(P.n_hops, L, P.nrw_nd_max, P.n_re_pad, P.nrw_h_stride, P.nrw_halo).total;

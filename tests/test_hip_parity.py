@@ -127,6 +127,16 @@ RANDOM_CASES = [
     S.case_spec("rnd_2hop_fullband", 273, [S.hop_spec([1, 5], 0, 273, 0, 7), S.hop_spec([8, 12], 0, 273, 7, 7)], seed=117),
     S.case_spec("rnd_2hop_250prb_3dmrs", 273, [S.hop_spec([0, 2, 5], 0, 250, 0, 7), S.hop_spec([8, 10, 13], 23, 250, 7, 7)], smoothing="none", seed=118),
     S.case_spec("rnd_3dmrs_2hop_40prb", 106, [S.hop_spec([0, 3, 6], 2, 40, 0, 7), S.hop_spec([7, 10, 13], 60, 40, 7, 7)], seed=109),
+    # re-read path (2-4 layers, or more DM-RS symbols than the register tiers hold): its LS / residual stages are specialised for
+    # 1..4 DM-RS symbols per hop (every load of a pilot RE requested together) and keep a run-time symbol loop beyond that
+    S.case_spec("rnd_5dmrs_30prb", 106, [S.hop_spec([1, 3, 6, 9, 12], 40, 30)], seed=119),                                      # 5 symbols: run-time loop
+    S.case_spec("rnd_6dmrs_L2_40prb", 106, [S.hop_spec([0, 2, 5, 7, 10, 13], 11, 40)], n_layers=2, smoothing="none", seed=120),
+    S.case_spec("rnd_5dmrs_3prb", 52, [S.hop_spec([1, 3, 6, 9, 12], 40, 3)], seed=121),                                         # ... on the wave-per-item kernel
+    S.case_spec("rnd_L2_2hop_100prb_3dmrs", 273, [S.hop_spec([0, 3, 6], 10, 100, 0, 7), S.hop_spec([7, 10, 13], 150, 100, 7, 7)], n_layers=2, seed=122),
+    S.case_spec("rnd_L4_2hop_136prb", 273, [S.hop_spec([1, 5], 0, 136, 0, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1]),
+                                            S.hop_spec([8, 12], 137, 136, 7, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1])], n_layers=4, seed=123),
+    S.case_spec("rnd_L3_1dmrs_80prb", 106, [S.hop_spec([3], 20, 80, re_masks=[S.TYPE1_CDM0, S.TYPE1_CDM1])], n_layers=3, smoothing="none", seed=124),
+    S.case_spec("rnd_L2_4dmrs_60prb", 106, [S.hop_spec([0, 4, 8, 12], 30, 60)], n_layers=2, seed=125),
 ]
 
 

@@ -145,6 +145,14 @@ def test_host_derivation_register_path_and_limits(lib):
     assert E.derive_host(h1, h2, cfg, 1.0, 1, 52, 14).contig[0] == 0
 
 
+def test_wave_per_item_kernel_takes_at_most_four_dmrs_symbols_per_hop(lib):
+    """The reference accepts any DMRSsymbols mask (T:564-568); the wave-per-item kernel's per-hop phasor tables hold four
+    symbols, so a narrow hop with five of them must keep the workgroup kernels (tests/test_hip_parity.py runs both)."""
+    for dm, narrow in (([2, 5, 8, 11], 1), ([1, 3, 6, 9, 12], 0)):
+        h1, h2, cfg = S.numpy_hops(S.case_spec("x", 52, [S.hop_spec(dm, 40, 3)]))
+        assert E.derive_host(h1, h2, cfg, 1.0, 1, 52, 14).narrow == narrow
+
+
 def test_shipped_library_ignores_tuning_knobs(lib, monkeypatch):
     """include/ce_hip.h "Tuning knobs": only the diagnostic build (libce_hip_knobs.so, -DCE_TUNING_KNOBS) reads the
     environment at plan creation; a stray variable in a user's environment cannot change the shipped library's kernel

@@ -101,6 +101,17 @@ def golden_cases():
         # iterated exactly, and 12-symbol grids (no CFO ramp possible: one DM-RS symbol / compensation off)
         (CS("cnn_case4like_fullslot_hops", 52, [H([0, 4], 3, 3, 0, 14), H([8, 12], 28, 3, 0, 14)], scs=15e3, seed=40), "C", 2),
         (dict(CS("cnn_type2_overlap_hops", 52, [H([1, 4], 5, 8, 0, 10, [S.TYPE2_CDM0]), H([8, 12], 9, 8, 6, 8, [S.TYPE2_CDM0])], n_layers=2, seed=41), cnn_alpha=0.3), "C", 1),
+        # grids of neither 14 nor 12 symbols (the generic element-wise writer) and hops with more DM-RS symbols than any NR configuration
+        # has (the reference takes any DMRSsymbols mask, T:564-568): outside the fuzzer's draw, so pinned here
+        (CS("sym13_25prb_nocfo", 52, [H([2, 9], 10, 25, 0, 13)], n_sym=13, cfo_compensate=False, seed=70), "T", 2),
+        (CS("sym7_2hop_6prb_1dmrs", 52, [H([1], 4, 6, 0, 3), H([5], 30, 6, 3, 4)], n_sym=7, seed=71), "T", 2),
+        (CS("sym13_layers2_2hop_nocfo", 52, [H([1, 4], 3, 12, 0, 6), H([7, 10], 30, 12, 6, 7)], n_layers=2, n_sym=13, cfo_compensate=False, seed=72), "T", 1),
+        (CS("sym10_100prb_1dmrs", 273, [H([4], 60, 100, 0, 10)], n_sym=10, smoothing="mean", seed=73), "T", 1),
+        (CS("dmrs5_3prb", 52, [H([1, 3, 6, 9, 12], 40, 3)], seed=74), "T", 2),
+        (CS("dmrs6_layers2_40prb", 106, [H([0, 2, 5, 7, 10, 13], 11, 40)], n_layers=2, smoothing="none", seed=75), "T", 1),
+        (CS("dmrs5_2hop_layers4_20prb", 106, [H([0, 1, 2, 4, 6], 5, 20, 0, 7, BOTH), H([7, 9, 10, 12, 13], 60, 20, 7, 7, BOTH)], n_layers=4, seed=76), "T", 1),
+        (CS("dmrs14_8prb", 52, [H(list(range(14)), 20, 8)], seed=77), "T", 1),
+        (CS("cnn_13sym_1dmrs", 52, [H([3], 5, 6, 0, 13)], n_sym=13, seed=78), "C", 2),
         (CS("cnn_12sym_1dmrs", 52, [H([3], 5, 6, 0, 12)], n_sym=12, seed=42), "C", 2),
         (CS("cnn_12sym_type2_nocfo", 52, [H([2, 9], 20, 4, 1, 10, [S.TYPE2_CDM0])], n_sym=12, cfo_compensate=False, smoothing="mean", seed=43), "C", 1),
         (CS("cnn_comb2_odd_2hop", 52, [H([3], 0, 5, 0, 7, [S.TYPE1_CDM1]), H([10], 47, 5, 7, 7, [S.TYPE1_CDM1])], smoothing="mean", seed=27), "C", 1),
