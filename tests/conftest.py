@@ -126,6 +126,9 @@ def check_outputs(got_ch, got_scalars, ref_ch, ref_scalars, tol_ch, tol_sc, what
     TA must be bit-identical (an integer bin index through the reference's two float64 divisions, T:698);
     cfo NaN <=> "not estimated"."""
     scale = float(np.abs(ref_ch).max())
+    if scale == 0.0:                                     # an all-zero grid (fixtures zero_grid*): the estimate must be exactly zero too
+        assert not np.any(got_ch), f"{what}: the reference's estimate is all zeros, this one is not"
+        scale = 1.0
     err = float(np.abs(got_ch - ref_ch).max()) / scale
     assert err <= tol_ch, f"{what}: ch_est rel-max err {err:.3e} > {tol_ch:.1e}"
     noise, rsrp, epre, ta, cfo = [float(x) for x in got_scalars]

@@ -112,6 +112,23 @@ def golden_cases():
         (CS("dmrs5_2hop_layers4_20prb", 106, [H([0, 1, 2, 4, 6], 5, 20, 0, 7, BOTH), H([7, 9, 10, 12, 13], 60, 20, 7, 7, BOTH)], n_layers=4, seed=76), "T", 1),
         (CS("dmrs14_8prb", 52, [H(list(range(14)), 20, 8)], seed=77), "T", 1),
         (CS("cnn_13sym_1dmrs", 52, [H([3], 5, 6, 0, 13)], n_sym=13, seed=78), "C", 2),
+        # inputs of unusual scale, geometry and timing (a 4th element transforms the generated grids before the reference runs)
+        (CS("grid1prb_filter", 1, [H([2, 11], 0, 1)], seed=80), "T", 2),
+        (CS("grid2prb_mean_layers2", 2, [H([2, 11], 0, 2)], n_layers=2, smoothing="mean", seed=81), "T", 1),
+        (CS("grid7prb_2hop", 7, [H([1, 5], 0, 3, 0, 7), H([8, 12], 4, 3, 7, 7)], seed=82), "T", 1),
+        (CS("grid275prb_none", 275, [H([2, 11], 0, 275)], smoothing="none", seed=83), "T", 1),
+        (CS("scs120_25prb", 52, [H([2, 11], 10, 25)], scs=120e3, delay_ns=40.0, cfo_hz=900.0, seed=84), "T", 2),
+        (CS("beta_half_12prb", 52, [H([2, 7, 11], 10, 12)], beta=0.5, seed=85), "T", 1),
+        (CS("advance_300ns_25prb", 52, [H([2, 11], 10, 25)], delay_ns=-300.0, seed=86), "T", 2),
+        (CS("advance_2hop_layers2", 52, [H([1, 5], 3, 6, 0, 7), H([8, 12], 30, 6, 7, 7)], n_layers=2, delay_ns=-150.0, seed=87), "T", 1),
+        (CS("delay_beyond_window", 52, [H([2, 11], 10, 25)], delay_ns=3000.0, seed=88), "T", 2),
+        (CS("noiseless_40prb", 106, [H([2, 11], 20, 40)], noise_var=0.0, seed=89), "T", 1),
+        (CS("cfo_3khz_4dmrs", 52, [H([0, 4, 8, 12], 8, 16)], cfo_hz=3000.0, seed=90), "T", 2),
+        (CS("tiny_amplitude", 52, [H([2, 11], 10, 12)], seed=91), "T", 1, dict(grid_scale=1e-6)),
+        (CS("huge_amplitude_layers2", 52, [H([2, 11], 10, 12)], n_layers=2, seed=92), "T", 1, dict(grid_scale=1e6)),
+        (CS("zero_grid", 52, [H([2, 11], 10, 12)], seed=93), "T", 1, dict(grid_scale=0.0)),
+        (CS("zero_grid_2hop_1dmrs", 52, [H([2], 3, 3, 0, 7), H([9], 28, 3, 7, 7)], seed=94), "T", 1, dict(grid_scale=0.0)),
+        (CS("cnn_advance_6prb", 52, [H([3, 10], 5, 6)], delay_ns=-250.0, seed=95), "C", 1),
         (CS("cnn_12sym_1dmrs", 52, [H([3], 5, 6, 0, 12)], n_sym=12, seed=42), "C", 2),
         (CS("cnn_12sym_type2_nocfo", 52, [H([2, 9], 20, 4, 1, 10, [S.TYPE2_CDM0])], n_sym=12, cfo_compensate=False, smoothing="mean", seed=43), "C", 1),
         (CS("cnn_comb2_odd_2hop", 52, [H([3], 0, 5, 0, 7, [S.TYPE1_CDM1]), H([10], 47, 5, 7, 7, [S.TYPE1_CDM1])], smoothing="mean", seed=27), "C", 1),
@@ -143,10 +160,12 @@ def main():
     out_dir.mkdir(parents=True, exist_ok=True)
     only = set(sys.argv[1:])          # optional: regenerate just the named fixtures (MANIFEST.json is updated, not rewritten)
     manifest = json.loads((out_dir / "MANIFEST.json").read_text()) if only and (out_dir / "MANIFEST.json").exists() else {}
-    for case, variant, n_items in golden_cases():
+    for case, variant, n_items, *mod in golden_cases():
         if only and case["name"] not in only:
             continue
         b = S.build_case(case, n_items)
+        if mod and "grid_scale" in mod[0]:
+            b.grids = (b.grids * np.float32(mod[0]["grid_scale"])).astype(np.complex64)
         cols = sorted({s for h in case["hops"] for s in h["dmrs_symbols"]})
         grids = np.zeros_like(b.grids)
         grids[:, :, cols] = b.grids[:, :, cols]
