@@ -17,9 +17,12 @@ PAIRS = [[S.TYPE1_CDM0, S.TYPE1_CDM1], [S.TYPE2_CDM0, S.TYPE2_CDM1], [S.TYPE2_CD
          [[1, 0, 0, 0] * 3, [0, 1, 0, 0] * 3], [S.TYPE1_CDM1, S.TYPE1_CDM0]]
 
 
-def draw(rng, max_grid=273):
-    """One random case: returns ``(case, extras)``; ``extras`` = interp, layout_ref, cnn_alpha, mmse parameters."""
-    grid = int(rng.choice([g for g in (6, 25, 52, 106, 273) if g <= max_grid]))
+def draw(rng, max_grid=273, wide=False):
+    """One random case: returns ``(case, extras)``; ``extras`` = interp, layout_ref, cnn_alpha, mmse parameters.
+    ``wide`` (tools/fuzz_parity.py --wide; never the suite's pinned slice, whose draws must not move): also what no NR
+    configuration has but the reference accepts -- up to 6 DM-RS symbols per hop, grids of 7 / 10 / 13 symbols, any grid
+    width from 1 to 275 PRB, timing advances, delays beyond the examined window, CFOs of kHz, other beta values."""
+    grid = int(rng.choice([g for g in ((1, 2, 3, 5, 7, 13, 24, 52, 100, 270, 275) if wide else (6, 25, 52, 106, 273)) if g <= max_grid]))
     layers = int(rng.choice([1, 1, 1, 2, 3, 4]))
     masks = [SINGLE[rng.integers(len(SINGLE))]] if layers <= 2 else PAIRS[rng.integers(len(PAIRS))]
     n_hops = int(rng.choice([1, 1, 2]))
@@ -31,6 +34,8 @@ def draw(rng, max_grid=273):
     for h in range(n_hops):
         lo, hi = (0, 14) if n_hops == 1 else ((0, 7) if h == 0 else (7, 14))
         nd = int(rng.integers(1, 5)) if n_hops == 1 else int(rng.integers(1, 4))
+        if wide and rng.random() < 0.3:
+            nd = int(rng.integers(4, 7))
         dm = sorted(rng.choice(np.arange(lo, hi), size=min(nd, hi - lo), replace=False).tolist())
         if n_hops == 1:
             start = int(rng.integers(0, 3)) if rng.random() < 0.3 else 0
@@ -47,21 +52,27 @@ def draw(rng, max_grid=273):
         k = min(len(hops[0]["dmrs_symbols"]), len(hops[1]["dmrs_symbols"]))
         hops[0]["dmrs_symbols"], hops[1]["dmrs_symbols"] = hops[0]["dmrs_symbols"][:k], hops[1]["dmrs_symbols"][:k]
     n_sym = 14 if rng.random() < 0.88 else 12       # 12: element-wise writer; no CFO ramp possible (T:928-929)
-    if n_sym == 12:
+    if wide and rng.random() < 0.25:
+        n_sym = int(rng.choice([7, 10, 13]))
+    if n_sym != 14:
         for h in hops:
-            h["dmrs_symbols"] = sorted({min(s, 11) for s in h["dmrs_symbols"]})
-            h["start_symbol"] = min(h["start_symbol"], 11)
-            h["n_alloc"] = min(h["n_alloc"], 12 - h["start_symbol"])
+            h["dmrs_symbols"] = sorted({min(s, n_sym - 1) for s in h["dmrs_symbols"]})
+            h["start_symbol"] = min(h["start_symbol"], n_sym - 1)
+            h["n_alloc"] = min(h["n_alloc"], n_sym - h["start_symbol"])
         if n_hops == 2 and set(hops[0]["dmrs_symbols"]) & set(hops[1]["dmrs_symbols"]):
             n_sym = 14
             for h in hops:                           # restore a valid 14-symbol description
                 h["n_alloc"] = min(h["n_alloc"], 14 - h["start_symbol"])
     smoothing = str(rng.choice(["none", "mean", "filter", "filter", "mmse"])) if interp == "linear" else str(rng.choice(["none", "mean", "filter"]))
     any_cfo = any(len(h["dmrs_symbols"]) >= 2 for h in hops)
-    cfo_comp = bool(rng.random() < 0.8) and not (n_sym == 12 and any_cfo)   # the reference cannot ramp a 12-symbol grid
+    cfo_comp = bool(rng.random() < 0.8) and not (n_sym != 14 and any_cfo)   # the reference cannot ramp a grid of other than 14 symbols
     case = S.case_spec("fuzz", grid, hops, n_layers=layers, smoothing=smoothing, n_sym=n_sym, cfo_compensate=cfo_comp,
                        scs=float(rng.choice([15e3, 30e3, 60e3])), seed=int(rng.integers(1 << 30)),
                        cfo_hz=float(rng.uniform(-400, 400)), delay_ns=float(rng.uniform(0, 400)))
+    if wide:
+        case["delay_ns"] = float(rng.choice([rng.uniform(-400, 400), rng.uniform(-400, 0), rng.uniform(1500, 6000)]))
+        case["cfo_hz"] = float(rng.choice([rng.uniform(-400, 400), rng.uniform(-4000, 4000)]))
+        case["beta"] = float(rng.choice([1.4125, 0.5, 1.0, 2.0]))
     extras = dict(interp=interp, layout_ref=bool(rng.random() < 0.3),
                   cnn_alpha=float(rng.choice([0.0, 0.4])) if interp == "cnn" else None,
                   mmse=(float(rng.choice([0.3e-6, 1.2e-6])), float(rng.choice([0.01, 0.1]))) if smoothing == "mmse" else None)

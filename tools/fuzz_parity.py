@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzer, long form (GPU box): random slot geometries through the HIP estimator and the CPU oracle.
 
-    python tools/fuzz_parity.py [--n 2000] [--seed 0] [--max-grid 273]
+    python tools/fuzz_parity.py [--n 2000] [--seed 0] [--max-grid 273] [--wide]
 
 Same generator and comparison protocol as the suite's bounded slice (tests/fuzz_cases.py, tests/test_hip_fuzz.py);
 prints one line per disagreement with the case as JSON and a summary.  Exit code 1 on any disagreement."""
@@ -21,12 +21,13 @@ def main():
     ap.add_argument("--n", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-grid", type=int, default=273)
+    ap.add_argument("--wide", action="store_true", help="also draw what no NR configuration has but the reference accepts (tests/fuzz_cases.py: draw)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     bad = unsupported = raised = ties = 0
     for i in range(a.n):
         rng = np.random.default_rng([a.seed, i])
-        case, extras = F.draw(rng, a.max_grid)
+        case, extras = F.draw(rng, a.max_grid, a.wide)
         tag = json.dumps(dict(case=case, extras=extras))
         b = F.realize(case, extras)
         want, stages, werr = [], [], None

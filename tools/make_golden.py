@@ -128,6 +128,8 @@ def golden_cases():
         (CS("huge_amplitude_layers2", 52, [H([2, 11], 10, 12)], n_layers=2, seed=92), "T", 1, dict(grid_scale=1e6)),
         (CS("zero_grid", 52, [H([2, 11], 10, 12)], seed=93), "T", 1, dict(grid_scale=0.0)),
         (CS("zero_grid_2hop_1dmrs", 52, [H([2], 3, 3, 0, 7), H([9], 28, 3, 7, 7)], seed=94), "T", 1, dict(grid_scale=0.0)),
+        (dict(CS("cfo_alias_cancel_7prb", 7, [H([1, 3, 4, 12], 0, 7, re_masks=[S.TYPE1_CDM1])], scs=15e3, beta=2.0, seed=837297901, cfo_hz=-3569.6354489162695,
+                 delay_ns=-356.07099071874416)), "T", 2),   # found by tools/fuzz_parity.py --wide (seed 9403, case 4462): item 1's estimate cancels to 1 / 128 of its input
         (CS("cnn_advance_6prb", 52, [H([3, 10], 5, 6)], delay_ns=-250.0, seed=95), "C", 1),
         (CS("cnn_12sym_1dmrs", 52, [H([3], 5, 6, 0, 12)], n_sym=12, seed=42), "C", 2),
         (CS("cnn_12sym_type2_nocfo", 52, [H([2, 9], 20, 4, 1, 10, [S.TYPE2_CDM0])], n_sym=12, cfo_compensate=False, smoothing="mean", seed=43), "C", 1),
