@@ -1394,25 +1394,25 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
         case 2: ls_pass(std::integral_constant<int, 2>{}); break;
         case 3: ls_pass(std::integral_constant<int, 3>{}); break;
         case 4: ls_pass(std::integral_constant<int, 4>{}); break;
-        default:
-      for (int k = tid; k < n_re; k += NT) {
+        default:   // any other count (the reference takes any DMRSsymbols mask, T:564-568): one symbol after the other
+          for (int k = tid; k < n_re; k += NT) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int64_t sc = pilot_sc(pmc[c], re_idx, k);
-          float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
-          for (int s = 0; s < n_dmrs; ++s) {
-            const float2 x = rx[sc * a.rs_sc + lh.dmrs_sym[s] * a.rs_sym];
-            epre_part += x.x * x.x + x.y * x.y;
-            const float2 rn = rot_neg[s];
-            const int64_t pb = k * a.ps_re + (lh.pil_sym0 + s) * a.ps_sym;
-            acc0 = cadd(acc0, cmul(cmul_conj(x, pil[pb + (2 * c) * a.ps_l]), rn));
-            if (2 * c + 1 < L) acc1 = cadd(acc1, cmul(cmul_conj(x, pil[pb + (2 * c + 1) * a.ps_l]), rn));
+            for (int c = 0; c < NC; ++c) {
+              const int64_t sc = pilot_sc(pmc[c], re_idx, k);
+              float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+              for (int s = 0; s < n_dmrs; ++s) {
+                const float2 x = rx[sc * a.rs_sc + lh.dmrs_sym[s] * a.rs_sym];
+                epre_part += x.x * x.x + x.y * x.y;
+                const float2 rn = rot_neg[s];
+                const int64_t pb = k * a.ps_re + (lh.pil_sym0 + s) * a.ps_sym;
+                acc0 = cadd(acc0, cmul(cmul_conj(x, pil[pb + (2 * c) * a.ps_l]), rn));
+                if (2 * c + 1 < L) acc1 = cadd(acc1, cmul(cmul_conj(x, pil[pb + (2 * c + 1) * a.ps_l]), rn));
+              }
+              Ph[(2 * c) * n_re_pad + k] = make_float2(acc0.x / beta_f / n_dmrs_f, acc0.y / beta_f / n_dmrs_f);
+              if (2 * c + 1 < L)
+                Ph[(2 * c + 1) * n_re_pad + k] = make_float2(acc1.x / beta_f / n_dmrs_f, acc1.y / beta_f / n_dmrs_f);
+            }
           }
-          Ph[(2 * c) * n_re_pad + k] = make_float2(acc0.x / beta_f / n_dmrs_f, acc0.y / beta_f / n_dmrs_f);
-          if (2 * c + 1 < L)
-            Ph[(2 * c + 1) * n_re_pad + k] = make_float2(acc1.x / beta_f / n_dmrs_f, acc1.y / beta_f / n_dmrs_f);
-        }
-      }
       }
     }
     __syncthreads();
@@ -1695,29 +1695,29 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
           case 2: resid_pass(std::integral_constant<int, 2>{}); break;
           case 3: resid_pass(std::integral_constant<int, 3>{}); break;
           case 4: resid_pass(std::integral_constant<int, 4>{}); break;
-          default:
-        for (int k = tid; k < n_re; k += NT) {
+          default:   // any other count: one symbol after the other
+            for (int k = tid; k < n_re; k += NT) {
 #pragma unroll
-          for (int l = 0; l < L; ++l) {
-            const float2 v = Ph[l * n_re_pad + k];
-            rsrp_part += v.x * v.x + v.y * v.y;
-          }
+              for (int l = 0; l < L; ++l) {
+                const float2 v = Ph[l * n_re_pad + k];
+                rsrp_part += v.x * v.x + v.y * v.y;
+              }
 #pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const int64_t sc = pilot_sc(pmc[c], re_idx, k);
-            const float2 h0 = Ph[(2 * c) * n_re_pad + k];
-            const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * n_re_pad + k] : make_float2(0.f, 0.f);
-            for (int s = 0; s < n_dmrs; ++s) {
-              const float2 x = rx[sc * a.rs_sc + lh.dmrs_sym[s] * a.rs_sym];
-              const float2 rp = rot_pos[s];
-              const int64_t pb = k * a.ps_re + (lh.pil_sym0 + s) * a.ps_sym;
-              float2 est = cmul(pil[pb + (2 * c) * a.ps_l], cmul(h0, rp));
-              if (2 * c + 1 < L) est = cadd(est, cmul(pil[pb + (2 * c + 1) * a.ps_l], cmul(h1, rp)));
-              const float dr = x.x - beta_f * est.x, di = x.y - beta_f * est.y;
-              noise_part += dr * dr + di * di;
+              for (int c = 0; c < NC; ++c) {
+                const int64_t sc = pilot_sc(pmc[c], re_idx, k);
+                const float2 h0 = Ph[(2 * c) * n_re_pad + k];
+                const float2 h1 = (2 * c + 1 < L) ? Ph[(2 * c + 1) * n_re_pad + k] : make_float2(0.f, 0.f);
+                for (int s = 0; s < n_dmrs; ++s) {
+                  const float2 x = rx[sc * a.rs_sc + lh.dmrs_sym[s] * a.rs_sym];
+                  const float2 rp = rot_pos[s];
+                  const int64_t pb = k * a.ps_re + (lh.pil_sym0 + s) * a.ps_sym;
+                  float2 est = cmul(pil[pb + (2 * c) * a.ps_l], cmul(h0, rp));
+                  if (2 * c + 1 < L) est = cadd(est, cmul(pil[pb + (2 * c + 1) * a.ps_l], cmul(h1, rp)));
+                  const float dr = x.x - beta_f * est.x, di = x.y - beta_f * est.y;
+                  noise_part += dr * dr + di * di;
+                }
+              }
             }
-          }
-        }
         }
       }
       double v[3] = {(double)epre_part, (double)noise_part, (double)rsrp_part};
