@@ -379,3 +379,56 @@ def test_hip_cnn_closed_form_for_converged_masks(mask, layers, smoothing):
         ref = O.srs_channel_estimator(b.grids[it], b.pilots, b.beta, b.hop1, b.hop2, b.config, interp="cnn")
         got = [sc[0][it], sc[1][it], sc[2][it], sc[3][it], sc[4][it]]
         check_outputs(ch[it], got, ref[0], list(ref[1:]), TOL_CH, TOL_SC, f"cnnfp_{mask}[{it}]")
+
+
+_VIEW_CASES = [
+    S.case_spec("view_filter_24prb", 52, [S.hop_spec([2, 11], 3, 24)], seed=301),                                            # register tier
+    S.case_spec("view_L2_2hop_6prb", 52, [S.hop_spec([1, 5], 3, 6, 0, 7), S.hop_spec([8, 12], 30, 6, 7, 7)], n_layers=2, seed=302),   # wave-per-item kernel
+    S.case_spec("view_273prb", 273, [S.hop_spec([2, 11], 0, 273)], seed=303),                                                # the headline's kernel
+    S.case_spec("view_L4_60prb_3dmrs", 106, [S.hop_spec([2, 7, 11], 20, 60, re_masks=[S.TYPE1_CDM0, S.TYPE1_CDM1])], n_layers=4, seed=304),   # re-read path
+]
+
+
+@pytest.mark.parametrize("case", _VIEW_CASES, ids=[c["name"] for c in _VIEW_CASES])
+def test_strided_and_offset_views_give_the_same_bits(case):
+    """The boundary takes element strides and a base pointer (include/ce_hip.h): slices of larger buffers, odd storage offsets
+    (a base pointer aligned to 8 bytes only), row pitches that are not a multiple of 16 bytes and pilots cut out of a wider
+    tensor must give bit for bit what the dense tensors give -- nothing in the kernels may assume more than the element's
+    own alignment or a unit stride."""
+    dev = _dev()
+    R = 3
+    b = S.build_case(case, R)
+    n_sc, n_sym = b.grids.shape[1], b.grids.shape[2]
+    dense = torch.as_tensor(b.grids, device=dev)[None]                                  # [1, R, n_sc, n_sym]
+    pil = torch.as_tensor(b.pilots, device=dev)
+    ref = E.estimate(dense, pil, b.beta, b.hop1, b.hop2, b.config)
+    torch.cuda.synchronize()
+
+    def same(out, what):
+        for nm, g, r in zip(("ch_est", "noise", "rsrp", "epre", "ta", "cfo"), out, ref):
+            if g.numel() or r.numel():
+                gi, ri = (torch.view_as_real(g), torch.view_as_real(r)) if g.is_complex() else (g.view(torch.int64), r.view(torch.int64))
+                assert torch.equal(gi, ri), f"{case['name']}: {what}: {nm} differs from the dense call"
+
+    # (a) [sc][sym] layout at an odd element offset of a flat buffer
+    flat = torch.zeros(dense.numel() + 1, dtype=torch.complex64, device=dev)
+    va = flat[1:].view(dense.shape)
+    va.copy_(dense)
+    same(E.estimate(va, pil, b.beta, b.hop1, b.hop2, b.config), "odd storage offset")
+    # (b) a slice of a larger [slots][ports][sc][sym] buffer: every other port, subcarriers 12 .. 12 + n_sc, symbols 1 .. 1 + n_sym
+    big = torch.randn(2, 2 * R, n_sc + 24, n_sym + 3, dtype=torch.complex64, device=dev)
+    vb = big[1:2, ::2, 12:12 + n_sc, 1:1 + n_sym]
+    vb.copy_(dense)
+    same(E.estimate(vb, pil, b.beta, b.hop1, b.hop2, b.config), "slice of a larger buffer")
+    # (c) [sym][sc] layout with a row pitch of n_sc + 1 elements (rows aligned to 8 bytes only), at an odd offset
+    buf = torch.zeros(1 + R * n_sym * (n_sc + 1), dtype=torch.complex64, device=dev)
+    vc = buf[1:].view(1, R, n_sym, n_sc + 1)[..., :n_sc].permute(0, 1, 3, 2)
+    vc.copy_(dense)
+    same(E.estimate(vc, pil, b.beta, b.hop1, b.hop2, b.config), "sym-major rows with an odd pitch")
+    # (d) pilots cut out of a wider tensor: one more layer and one more symbol than used, odd offset
+    n_re, n_dm, L = pil.shape
+    wide = torch.randn(1 + n_re * (n_dm + 1) * (L + 1), dtype=torch.complex64, device=dev)
+    vp = wide[1:].view(n_re, n_dm + 1, L + 1)[:, :n_dm, :L]
+    vp.copy_(pil)
+    same(E.estimate(dense, vp, b.beta, b.hop1, b.hop2, b.config), "pilots sliced out of a wider tensor")
+    same(E.estimate(vc, vp, b.beta, b.hop1, b.hop2, b.config), "both")
