@@ -15,6 +15,7 @@ PyTorch is used for device memory and streams only; all arithmetic happens in
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import warnings
 from collections import OrderedDict
 from typing import Any, Optional, Tuple
@@ -61,6 +62,7 @@ class Plan:
 
 _PLAN_CACHE: "OrderedDict[Any, Plan]" = OrderedDict()
 _PLAN_CACHE_MAX = 64
+_PLAN_CACHE_LOCK = threading.Lock()
 
 
 def _hop_fields(hop, n_cdm: int):
@@ -191,10 +193,11 @@ def make_plan(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_s
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     key = (device.index,) + key
-    plan = _PLAN_CACHE.get(key)
-    if plan is not None:                        # steady state: no descriptor, no ctypes buffers, no library call
-        _PLAN_CACHE.move_to_end(key)
-        return plan
+    with _PLAN_CACHE_LOCK:                      # host threads may share the cache (a get / move_to_end pair must not straddle another thread's eviction)
+        plan = _PLAN_CACHE.get(key)
+        if plan is not None:                    # steady state: no descriptor, no ctypes buffers, no library call
+            _PLAN_CACHE.move_to_end(key)
+            return plan
     desc, keep = _fill_desc(vals, device.index)
     handle = C.c_void_p()
     with torch.cuda.device(device):
@@ -205,9 +208,10 @@ def make_plan(hop1, hop2, config, beta_dmrs, n_layers: int, n_prb_grid: int, n_s
     info = _lib.PlanInfo()
     lib.ce_plan_get_info(handle, C.byref(info))
     plan = Plan(handle.value, info, key, device, n_layers, n_sym)
-    _PLAN_CACHE[key] = plan
-    while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
-        _PLAN_CACHE.popitem(last=False)
+    with _PLAN_CACHE_LOCK:
+        _PLAN_CACHE[key] = plan                 # (two threads that missed together both built the plan: the later one stays, the other lives as long as its caller holds it)
+        while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
+            _PLAN_CACHE.popitem(last=False)
     return plan
 
 

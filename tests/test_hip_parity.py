@@ -432,3 +432,43 @@ def test_strided_and_offset_views_give_the_same_bits(case):
     vp.copy_(pil)
     same(E.estimate(dense, vp, b.beta, b.hop1, b.hop2, b.config), "pilots sliced out of a wider tensor")
     same(E.estimate(vc, vp, b.beta, b.hop1, b.hop2, b.config), "both")
+
+
+def test_host_threads_share_the_estimator():
+    """Four host threads call estimate() at once -- the same plan, different plans, and enough distinct plans to churn the plan
+    cache (its lookups and evictions are locked; plan creation and the launches run outside the lock and outside the GIL):
+    every result equals the serial one bit for bit."""
+    import threading
+    dev = _dev()
+    cases = [S.case_spec(f"thr{i}", 52, [S.hop_spec([2, 11], 1 + i % 20, 3 + i % 9)], n_layers=1 + i % 2, smoothing=("filter", "none", "mean")[i % 3], seed=400 + i)
+             for i in range(E._PLAN_CACHE_MAX + 24)]
+    built = [S.build_case(c, 2) for c in cases]
+    ins = [(torch.as_tensor(b.grids, device=dev)[None], torch.as_tensor(b.pilots, device=dev)) for b in built]
+    serial = []
+    for b, (g, p) in zip(built, ins):
+        serial.append([t.clone() for t in E.estimate(g, p, b.beta, b.hop1, b.hop2, b.config)])
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(w):
+        try:
+            torch.cuda.set_device(dev)
+            order = list(range(len(cases)))[w::2] + list(range(len(cases)))[::-1][w::3] + [0, 1, 2, 3] * 8   # overlapping subsets, the first plans hammered by everyone
+            for i in order:
+                b, (g, p) = built[i], ins[i]
+                out = E.estimate(g, p, b.beta, b.hop1, b.hop2, b.config)
+                torch.cuda.synchronize()
+                for nm, got, ref in zip(("ch_est", "noise", "rsrp", "epre", "ta", "cfo"), out, serial[i]):
+                    gi, ri = (torch.view_as_real(got), torch.view_as_real(ref)) if got.is_complex() else (got.view(torch.int64), ref.view(torch.int64))
+                    if not torch.equal(gi, ri):
+                        errors.append(f"thread {w}, case {i}: {nm} differs from the serial call")
+        except Exception as e:                      # noqa: BLE001 -- reported by the main thread
+            errors.append(f"thread {w}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    assert len(E._PLAN_CACHE) <= E._PLAN_CACHE_MAX
