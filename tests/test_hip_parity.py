@@ -472,3 +472,36 @@ def test_host_threads_share_the_estimator():
         t.join()
     assert not errors, errors[:5]
     assert len(E._PLAN_CACHE) <= E._PLAN_CACHE_MAX
+
+
+_GUARD_CASES = _VIEW_CASES + [
+    S.case_spec("guard_12sym_25prb", 52, [S.hop_spec([2, 9], 10, 25, 0, 12)], n_sym=12, cfo_compensate=False, seed=311),
+    S.case_spec("guard_13sym_2hop", 52, [S.hop_spec([1], 3, 12, 0, 6), S.hop_spec([8], 30, 12, 6, 7)], n_sym=13, seed=312),           # generic element-wise writer
+    S.case_spec("guard_1prb_grid", 1, [S.hop_spec([2, 11], 0, 1)], seed=313),
+    S.case_spec("guard_L3_2hop_100prb", 273, [S.hop_spec([1, 5], 0, 100, 0, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1]), S.hop_spec([8, 12], 173, 100, 7, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1])], n_layers=3, seed=314),
+]
+
+
+@pytest.mark.parametrize("interp", ["linear", "cnn"])
+@pytest.mark.parametrize("case", _GUARD_CASES, ids=[c["name"] for c in _GUARD_CASES])
+def test_outputs_stay_inside_their_buffers(case, interp):
+    """The response and the five scalar arrays carved out of guard-filled buffers (4096 elements either side), 2 slots x 3 ports
+    (6 items: a ragged last workgroup for the wave-per-item kernel): every guard element survives and the results are the bits of
+    an ordinary call.  (tools/fuzz_parity.py --guards does this for every drawn case.)"""
+    dev = _dev()
+    b = S.build_case(case, 6)
+    g = torch.as_tensor(b.grids, device=dev).view(2, 3, *b.grids.shape[1:])
+    p = torch.as_tensor(b.pilots, device=dev)
+    ref = E.estimate(g, p, b.beta, b.hop1, b.hop2, b.config, interp=interp)
+    G, n_ch, n_it = 4096, ref[0].numel(), ref[1].numel()
+    fc = torch.empty((n_ch + 2 * G,), dtype=torch.complex64, device=dev)
+    torch.view_as_real(fc).fill_(-7.25)
+    fs = torch.full((5, n_it + 2 * G), -7.25, dtype=torch.float64, device=dev)
+    outs = (fc[G:G + n_ch].view(ref[0].shape),) + tuple(fs[j, G:G + n_it].view(ref[1].shape) for j in range(5))
+    got = E.estimate(g, p, b.beta, b.hop1, b.hop2, b.config, interp=interp, out=outs)
+    torch.cuda.synchronize()
+    assert bool((torch.view_as_real(fc[:G]) == -7.25).all() and (torch.view_as_real(fc[G + n_ch:]) == -7.25).all()), "a store landed outside the response"
+    assert bool((fs[:, :G] == -7.25).all() and (fs[:, G + n_it:] == -7.25).all()), "a store landed outside a scalar array"
+    for x, y in zip(got, ref):
+        if x.numel() and y.numel():
+            assert torch.equal(torch.view_as_real(x) if x.is_complex() else x.view(torch.int64), torch.view_as_real(y) if y.is_complex() else y.view(torch.int64))
