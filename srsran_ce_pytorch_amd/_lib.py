@@ -83,7 +83,11 @@ EXTRA_FLAGS = {"ce_denoise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # PRB -7 %, iterated in-painting -5 %, 4 layers x 2 hops -2 %; the one-hop register units are indifferent and keep the default;
                # profiles/round3_noslp_ab.txt)
                "ce_inst_reg_h2_f0.hip": ["-fno-slp-vectorize"], "ce_inst_reg_h2_f1.hip": ["-fno-slp-vectorize"],
-               "ce_inst_gen_h1.hip": ["-fno-slp-vectorize"], "ce_inst_gen_h2.hip": ["-fno-slp-vectorize"]}
+               "ce_inst_gen_h2.hip": ["-fno-slp-vectorize"],
+               # the one-hop re-read unit also without the loop vectoriser (its staged writer's store loop otherwise pairs iterations into
+               # v_pk_mul/fma_f32 at ~50 register moves per 8 stores): 2 / 4 layers at full band -1 ... -2 % in two in-process A/Bs, bit-identical;
+               # the two-hop unit measured +2 % with it and keeps the vectoriser (profiles/round3_reread_batched_loads_ab.txt)
+               "ce_inst_gen_h1.hip": ["-fno-slp-vectorize", "-fno-vectorize"]}
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: Path | None = None) -> Path:
