@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Rewrites the two measured tables of DESIGN.md section 3 ("Measured (round 3 ...)") from the committed profile files, so the
 document cannot drift from them:  profiles/round3_summary.json + round3_bench_line.json + round3_geometry_counters.json (the lease of
-the final head) and profiles/round3_*_c1ce219.lease.* (the previous lease: the same kernels; profiles/round3_*_622852f.lease.* and *_cc40bd7.lease.* are earlier heads).  Prose around the tables is left alone.
+the final head) and profiles/round3_*_53d6648.lease.* (the previous lease: the same kernel sources, the slowest box of the round; *_c1ce219, *_622852f and *_cc40bd7 are earlier heads).  Prose around the tables is left alone.
 
     python tools/regen_design_tables.py        (tables sit between the <!-- lease-table --> / <!-- geometry-table --> markers)"""
 import json, re
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 P = ROOT / "profiles"
-sB, sA = json.loads((P / "round3_summary.json").read_text()), json.loads((P / "round3_summary_c1ce219.lease.json").read_text())
+sB, sA = json.loads((P / "round3_summary.json").read_text()), json.loads((P / "round3_summary_53d6648.lease.json").read_text())
 bB = json.loads((P / "round3_bench_line.json").read_text())
 geo = json.loads((P / "round3_geometry_counters.json").read_text())["geometries"]
 ALG = 13096452096
