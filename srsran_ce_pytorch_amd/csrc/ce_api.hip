@@ -535,6 +535,9 @@ static int plan_build(const ce_plan_desc* d, ce_plan** out, bool upload) {
         ((ce_lds_layout(P.n_hops, L, P.n_re_pad, sb2).total + 2047) & ~2047) * waves <= 160 * 1024) {  // LDS is granted in 2 KB steps (measured: 3 x 52 128 B fit a CU, 3 x 54 176 B do not)
       P.ta_lp = 2;
       P.scratch_bytes = sb2;
+    } else if (CE_TA_OVER_P && L >= 2 && d->n_hops == 2 && late && !ce_knob("CE_TA_LP1") && nres_max <= 8 && P.scratch_bytes >= 8 * ce_ta_row(late) * 8 &&
+               L * P.n_re_pad * 8 >= 8 * ce_ta_row(late) * 8) {
+      P.ta_over_p = 1;   // (e.g. 4 layers x 2 hops x 136 PRB: 52 KB of P, two workgroups per CU whatever the scratch -- six transform rounds instead of eight)
     }
   }
   // Register-path kernels that cannot also hold the DM-RS symbols in registers (ce_pilots_in_regs) park the current hop's

@@ -973,10 +973,15 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
       // residue blocks; the bin sums then add the layers' powers in layer order, as the one-at-a-time form does.
       constexpr bool HPAR_OK = NH == 2 && L == 1 && TA_LATE;  // elsewhere the hop of the passes stays wave-uniform (scalar registers)
       const bool hpar = HPAR_OK && npar == 2;
-      const int lpn = (L >= 2) ? lp->ta_lp : 1;
+      // (plan: ta_over_p) no room for a second set of residue blocks next to P: the last hop still runs two layers at a time, its
+      // second set laid over the FIRST hop's rows of P -- dead once that hop's transforms are done (this stage runs after the writer)
+      constexpr bool OVERP_OK = TA_LATE && NH == 2 && L >= 2;
+      const bool over_p = OVERP_OK && lp->ta_over_p && h0 == NH - 1;
+      const int lpn = (L >= 2) ? (over_p ? 2 : lp->ta_lp) : 1;
       const int sub = (lpn == 2 || hpar) ? (tid >> 7) : 0;
       const int ri = (lpn == 2 || hpar) ? ((tid >> 4) & 7) : (tid >> 4), a4 = tid & 15;
-      float2* scr = scratch + sub * (8 * TA_ROW);
+      float2* const set2 = over_p ? P : scratch + 8 * TA_ROW;   // the second set of residue blocks
+      float2* scr = sub ? set2 : scratch;
       // the hop whose passes this thread runs
       const CeDevHop& lh = lp->hop[h0 + (hpar ? sub : 0)];
       const float2* Ph = P + (h0 + (hpar ? sub : 0)) * L * n_re_pad;
@@ -1096,7 +1101,7 @@ __global__ __launch_bounds__(NT, ce_min_waves(NH, ND, KPT, FEAT, L)) void ce_est
           const CeDevHop& bh = lp->hop[h0];
 #pragma unroll 1
           for (int s2 = 0; s2 < lpn && l0 + s2 < L; ++s2) {
-            const float2* blocks = scratch + s2 * (8 * TA_ROW);
+            const float2* blocks = s2 ? set2 : scratch;
             if (b0 < NB) pw0 += bin_power(b0 < CE_TA_HALF ? b0 : CE_FFT_SIZE - NB + b0, blocks, bh.ta_nres, bh.ta_res_packed);
             if (b1 < NB) pw1 += bin_power(b1 < CE_TA_HALF ? b1 : CE_FFT_SIZE - NB + b1, blocks, bh.ta_nres, bh.ta_res_packed);
           }

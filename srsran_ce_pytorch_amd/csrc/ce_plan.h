@@ -60,6 +60,9 @@
                             // (no shape reaches it: with the DM-RS symbols fetched once per hop and parked in the LDS, three
                             // workgroups per CU beat two with everything in registers -- 3 symbols x 200 PRB: 4.09 -> 3.37 ms)
 #endif
+#ifndef CE_TA_OVER_P
+#define CE_TA_OVER_P 1      // plan: ta_over_p (the last hop's second set of TA residue blocks over the first hop's P); 0: A/B builds
+#endif
 #ifndef CE_CNNFP_STAGED
 #define CE_CNNFP_STAGED 1   // ce_dl_cnn's binomial closed form (cnn_comb2 == 2) in the staged writer: the linear fill is staged first, then the
                             // nine taps from LDS (0: nine interpolations per RE; A/B builds).  Kernel and host (scratch sizing) must agree.
@@ -167,7 +170,10 @@ struct alignas(16) CeDevPlan {
   int32_t narrow, nrw_nd_max;         // nrw_nd_max: most DM-RS symbols in a hop (sizes the per-wave staging rows)
   uint32_t nrw_magic_nre;             // floor(2^32 / n_re) + 1: idx / n_re == umulhi(idx, magic) for idx < 2^16
   int32_t nrw_h_stride;               // complex elements per (hop, layer) row of the interpolated response: widest hop band, even
-  int32_t nrw_halo, nrw_pad[3];       // slots on either side of a P row: the RC filter's reach (virtual pilots + zeros), 0 without the filter
+  int32_t nrw_halo;                   // slots on either side of a P row: the RC filter's reach (virtual pilots + zeros), 0 without the filter
+  int32_t ta_over_p;                  // 2-4 layers x 2 hops whose LDS has no room for a second set of TA residue blocks (ta_lp == 1): the LAST hop's transforms still
+                                      // run two layers at a time, the second set laid over the first hop's rows of P, which nobody reads once that hop's TA is done
+  int32_t nrw_pad[2];
   CeDevHop hop[CE_MAX_HOPS];
 };
 

@@ -28,6 +28,9 @@ CASES = [
     S.case_spec("tier_2hop_12prb", 52, [S.hop_spec([2], 3, 12, 0, 7), S.hop_spec([9], 30, 12, 7, 7)], seed=904),
     S.case_spec("tier_L2_40prb", 106, [S.hop_spec([2, 11], 20, 40)], n_layers=2, seed=905),
     S.case_spec("tier_2hop_L2_12prb", 52, [S.hop_spec([1, 5], 3, 12, 0, 7), S.hop_spec([8, 12], 30, 12, 7, 7)], n_layers=2, seed=906),
+    # 4 (and 3) layers x 2 wide hops: no LDS for a second set of TA residue blocks, the last hop's second set lies over the first hop's P (plan: ta_over_p; CE_TA_LP1 = one layer at a time)
+    S.case_spec("tier_2hop_L4_136prb", 273, [S.hop_spec([1, 5], 0, 136, 0, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1]), S.hop_spec([8, 12], 137, 136, 7, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1])], n_layers=4, seed=908),
+    S.case_spec("tier_2hop_L3_120prb", 273, [S.hop_spec([0, 3, 6], 20, 120, 0, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1]), S.hop_spec([7, 10, 13], 150, 120, 7, 7, [S.TYPE1_CDM0, S.TYPE1_CDM1])], n_layers=3, seed=909),
 ]
 
 CHILD = r'''
