@@ -29,7 +29,8 @@ def test_cpu_baseline_leg_runs_on_a_small_sample():
     out = bench.cpu_baseline(case, 2, target_core_seconds=0.2)
     assert out["unit"] == "slots/s" and out["kind"] == "port" and out["value"] > 0 and 1 <= out["cores"] <= 16
     # `value` is the loop-style ce_rule_baseline port (the baseline north_star names); the tensorized port sits next to it
-    assert out["flavour"].startswith("ce_rule_baseline") and out["tensorized_value"] > out["value"] and out["config0_ms"] > 0
+    # (no ordering between the two is asserted: 0.2 core-seconds on a busy host say nothing about speed)
+    assert out["flavour"].startswith("ce_rule_baseline") and out["tensorized_value"] > 0 and out["config0_ms"] > 0
     json.dumps(out)
     cnn = bench.cpu_baseline(case, 2, target_core_seconds=0.2, interp="cnn")
     assert cnn["flavour"] == "ce_dl_cnn" and cnn["value"] > 0 and "tensorized_value" not in cnn
