@@ -130,6 +130,16 @@ def golden_cases():
         (CS("zero_grid_2hop_1dmrs", 52, [H([2], 3, 3, 0, 7), H([9], 28, 3, 7, 7)], seed=94), "T", 1, dict(grid_scale=0.0)),
         (dict(CS("cfo_alias_cancel_7prb", 7, [H([1, 3, 4, 12], 0, 7, re_masks=[S.TYPE1_CDM1])], scs=15e3, beta=2.0, seed=837297901, cfo_hz=-3569.6354489162695,
                  delay_ns=-356.07099071874416)), "T", 2),   # found by tools/fuzz_parity.py --wide (seed 9403, case 4462): item 1's estimate cancels to 1 / 128 of its input
+        # the same ground for src/ce_dl_cnn.py
+        (CS("cnn_dmrs5_3prb", 52, [H([1, 3, 6, 9, 12], 40, 3)], seed=96), "C", 2),
+        (CS("cnn_dmrs6_type2_30prb", 106, [H([0, 2, 5, 7, 10, 13], 11, 30, re_masks=[S.TYPE2_CDM0])], smoothing="none", seed=97), "C", 1),
+        (CS("cnn_grid275prb_comb2", 275, [H([2, 11], 0, 275)], smoothing="none", seed=98), "C", 1),
+        (CS("cnn_grid1prb", 1, [H([2, 11], 0, 1)], seed=99), "C", 2),
+        (CS("cnn_13sym_2hop_layers2", 52, [H([1], 3, 12, 0, 6), H([8], 30, 12, 6, 7)], n_layers=2, n_sym=13, seed=100), "C", 1),
+        (CS("cnn_huge_amplitude", 52, [H([2, 11], 10, 12)], seed=101), "C", 1, dict(grid_scale=1e6)),
+        (CS("cnn_zero_grid", 52, [H([2, 11], 10, 12)], seed=102), "C", 1, dict(grid_scale=0.0)),
+        (CS("cnn_cfo_3khz_scs120", 52, [H([0, 4, 8, 12], 8, 16)], scs=120e3, cfo_hz=3000.0, delay_ns=30.0, seed=103), "C", 1),
+        (dict(CS("cnn_alpha_advance_type2", 52, [H([3, 10], 5, 9, re_masks=[S.TYPE2_CDM1])], delay_ns=-200.0, seed=104), cnn_alpha=0.4), "C", 1),
         (CS("cnn_advance_6prb", 52, [H([3, 10], 5, 6)], delay_ns=-250.0, seed=95), "C", 1),
         (CS("cnn_12sym_1dmrs", 52, [H([3], 5, 6, 0, 12)], n_sym=12, seed=42), "C", 2),
         (CS("cnn_12sym_type2_nocfo", 52, [H([2, 9], 20, 4, 1, 10, [S.TYPE2_CDM0])], n_sym=12, cfo_compensate=False, smoothing="mean", seed=43), "C", 1),
